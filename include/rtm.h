@@ -1,0 +1,164 @@
+/*
+ * rtm.h — C ABI of the MI355X-native path-tracing hot path for RaytracingMin scenes.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the seams this ABI
+ * replaces are (paths relative to the reference checkout):
+ *
+ *   png::Renderer::Renderer(SettingData&)              src/Renderer.h:11, src/Renderer.cpp:20-23
+ *   void png::Renderer::Render(std::string fileName)   src/Renderer.h:13, src/Renderer.cpp:200-258
+ *   png::vec3 png::PathTracing(Ray, SettingData&, fn)  src/Renderer.cpp:57-117
+ *   bool png::SphereObject::Intersect(...)             src/SettingData.cpp:197-226
+ *   png::LoadData::LoadData(std::string)               src/SettingData.cpp:6-12,129-186
+ *   stbi_write_bmp / stbi_write_jpg call sites         src/Renderer.cpp:251-257
+ *
+ * Conventions: plain C types only; the caller owns every buffer; nothing allocated inside is
+ * handed out; every entry point returns RTM_OK (0) or a negative rtm_status, never throws.
+ * "Device" pointers are HIP device pointers on the GPU selected in rtm_options.device; streams are
+ * hipStream_t passed as void*.
+ */
+#ifndef RTM_H
+#define RTM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTM_ABI_VERSION 1
+
+typedef enum rtm_status {
+    RTM_OK = 0,
+    RTM_ERR_INVALID_ARGUMENT = -1, /* null pointer, non-positive size, bad enum value          */
+    RTM_ERR_INVALID_SCENE = -2,    /* unsupported objectType, malformed numbers                 */
+    RTM_ERR_IO = -3,               /* file cannot be opened / written                           */
+    RTM_ERR_PARSE = -4,            /* JSON syntax or type error (reference: nlohmann exception) */
+    RTM_ERR_NO_DEVICE = -5,        /* no HIP device / HIP runtime failure at init               */
+    RTM_ERR_HIP = -6,              /* a HIP call failed; see rtm_last_error_detail()            */
+    RTM_ERR_CAPACITY = -7,         /* caller buffer too small                                   */
+    RTM_ERR_UNSUPPORTED = -8       /* valid request this build cannot serve                     */
+} rtm_status;
+
+/* png::Camera — src/SettingData.h:43-46.  fov is a float and is a tangent scale, not degrees
+ * (src/Renderer.cpp:207-208). */
+typedef struct rtm_camera {
+    double origin[3];
+    double target[3];
+    double up[3];
+    float fov;
+    float _pad;
+} rtm_camera;
+
+/* png::SphereObject + png::Material flattened — src/SettingData.h:8-17,25-32.
+ * radius is a float exactly like SphereObject::m_size. */
+typedef struct rtm_sphere {
+    double center[3];
+    double color[3];
+    double emission[3];
+    float radius;
+    float _pad;
+} rtm_sphere;
+
+/* png::SettingData minus the object vector — src/SettingData.h:47-51. */
+typedef struct rtm_settings {
+    int32_t width, height, samples, super_samples;
+    rtm_camera camera;
+} rtm_settings;
+
+enum { RTM_MODE_LITERAL = 0,  /* L0: HEAD as shipped (normal lost, recursion gets ::rand)       */
+       RTM_MODE_REPAIRED = 1  /* L1: the three one-line defects fixed    */ };
+
+typedef struct rtm_options {
+    int32_t mode;         /* RTM_MODE_*                                                        */
+    int32_t max_bounces;  /* <0: unlimited (reference recursion); k>=0: cast k+1 returns
+                             emission on hit without drawing (build extension)     */
+    uint64_t seed;        /* RNG seed (build-defined counter RNG, rtm_rng_u01 below)           */
+    int32_t row_begin;    /* first image row of this tile                                      */
+    int32_t row_end;      /* one past the last row; full image = [0, height)                   */
+    int32_t device;       /* HIP device ordinal                                                */
+    int32_t variant;      /* kernel variant, 0 = default (see rtm_variant_name)                */
+} rtm_options;
+
+/* Per-render counters (sum over the rendered tile); filled when the pointer is non-null. */
+typedef struct rtm_stats {
+    uint64_t samples;     /* primary samples traced = rows*width*SS*SS*S                       */
+    uint64_t casts;       /* PathTracing invocations (ray casts)                               */
+    uint64_t bounces;     /* casts that continued (RR passed)                                  */
+    uint64_t draws;       /* RNG draws consumed                                                */
+    double kernel_ms;     /* device time of the render kernel(s), HIP events on the stream     */
+} rtm_stats;
+
+/* ---- library ---- */
+int rtm_abi_version(void);
+const char* rtm_strerror(int status);
+const char* rtm_last_error_detail(void);   /* thread-local text of the last failure            */
+int rtm_device_count(int* count);          /* RTM_ERR_NO_DEVICE if the HIP runtime has none    */
+int rtm_num_variants(void);
+const char* rtm_variant_name(int variant);
+
+/* ---- the hot path: Renderer::Render's pixel/sample loop (src/Renderer.cpp:215-250) ----
+ * Renders rows [row_begin,row_end) of the image into caller-owned DEVICE buffers; any of the
+ * three outputs may be null.  Layout is the reference's: row-major, row 0 first, RGB interleaved
+ * (src/Renderer.cpp:246-248).  out_f64 holds Renderer::image bit-for-bit semantics (double);
+ * out_f32 is the same value rounded to float (the float3 accumulation buffer); out_u8 is the
+ * reference's 8-bit quantisation (src/Renderer.cpp:251-254).
+ * Asynchronous on `stream` unless stats != NULL (then it synchronises the stream to read the
+ * counters and timing).  Scene arrays are HOST pointers (tiny for shipped scenes) unless
+ * spheres_on_device != 0. */
+int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
+                      int spheres_on_device, const rtm_options* options, double* out_f64_dev,
+                      float* out_f32_dev, uint8_t* out_u8_dev, void* stream, rtm_stats* stats);
+
+/* Blocking convenience: same render, HOST output buffers (any may be null). */
+int rtm_render(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
+               const rtm_options* options, double* out_f64, float* out_f32, uint8_t* out_u8,
+               rtm_stats* stats);
+
+/* ---- per-ray seam: png::PathTracing (src/Renderer.cpp:57-117) for a batch of rays on device.
+ * Ray i uses the RNG stream keyed (seed, pixel = i, sample = 0).  Host buffers.
+ * org/dir: n*3 doubles; out_radiance: n*3; out_draws/out_casts: n (nullable). */
+int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options,
+                         const double* org, const double* dir, size_t n_rays,
+                         double* out_radiance, uint32_t* out_draws, uint32_t* out_casts);
+
+/* ---- per-call seam: SphereObject::Intersect (src/SettingData.cpp:197-226) on device.
+ * Pair i tests ray i against sphere i.  Host buffers.  out_t/out_normal are left untouched
+ * (caller-initialised) where out_hit[i]==0; in RTM_MODE_LITERAL out_normal is never written. */
+int rtm_intersect_batch(const rtm_sphere* spheres, const double* org, const double* dir,
+                        size_t n, int mode, int32_t* out_hit, double* out_t, double* out_normal);
+
+/* ---- the build-defined RNG (reference seeds std::mt19937 from random_device:
+ * src/Renderer.cpp:210-213, so there is no reference stream to match).  Host-side evaluation of
+ * draw `index` of stream (seed, pixel, sample); device side must agree (rtm_rng_batch). */
+double rtm_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index);
+int rtm_rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample,
+                  uint32_t n_draws, double* out /* n_pixels*n_draws, host, computed on device */);
+
+/* ---- host side: scene loading (png::LoadData, src/SettingData.cpp:6-12,129-186) ----
+ * Reads the reference's JSON schema.  literal_loader != 0 reproduces HEAD's position bug
+ * (src/SettingData.cpp:165-167: centre = (json_z, 0, 0)).  Shipped files load unchanged:
+ * missing "00 objectType" => sphere, objects without "00 position" skipped, "00 sample" accepted
+ * for "00 samples", missing samples/superSamples => 10 / 1.
+ * spheres may be NULL with capacity 0 to query *n_spheres. */
+int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,
+                        rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
+int rtm_scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* settings,
+                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
+/* LoadData::SaveSampleJson (src/SettingData.cpp:14-24,100-127): 960x540, samples 10, SS 4. */
+int rtm_scene_save_sample_json(const char* path);
+/* Stress scene of BASELINE config 5: SplitMix64(seed), n spheres. */
+int rtm_scene_make_stress(uint64_t seed, size_t n, rtm_settings* settings, rtm_sphere* spheres);
+
+/* ---- host side: image output (src/Renderer.cpp:251-257) ----
+ * rtm_quantise: u8 = (unsigned char)(255 * min(v, 1.0)) per component. */
+int rtm_quantise(const double* image, size_t n_values, uint8_t* out);
+/* stb_image_write-compatible signatures (w, h, comp = 3, RGB rows top-down). Return 1 on success
+ * like stb (0 on failure) so real stb can replace them. */
+int rtm_write_bmp(const char* filename, int w, int h, int comp, const void* data);
+int rtm_write_jpg(const char* filename, int w, int h, int comp, const void* data, int quality);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTM_H */
