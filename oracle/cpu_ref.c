@@ -310,6 +310,17 @@ void rtmo_sample_radiance(const rtm_settings* st, const rtm_sphere* spheres, siz
           out_radiance);
 }
 
+/* png::PathTracing on an arbitrary ray, drawing from the build RNG stream (seed, pixel, sample) */
+void rtmo_path_trace_stream(const rtm_sphere* spheres, size_t n, int mode, int max_bounces,
+                            const double org[3], const double dir[3], uint64_t seed,
+                            uint32_t pixel, uint32_t sample, double out_radiance[3],
+                            rtmo_counters* counters) {
+    pt_env env = {spheres, n, mode, max_bounces, counters};
+    rng_stream rs;
+    stream_init(&rs, seed_multiplier(seed), pixel, sample);
+    v3_to(path_trace(&env, v3_from(org), v3_from(dir), stream_next, &rs, 0, 0), out_radiance);
+}
+
 /* src/Renderer.cpp:222-248 for one pixel */
 static void render_pixel(const rtm_settings* st, const pt_env* env, v3 cx, v3 cy, v3 cz,
                          double fovx, double fovy, uint64_t seed_mult, int x, int y,

@@ -51,6 +51,12 @@ void rtmo_path_trace(const rtm_sphere* spheres, size_t n, int mode, int max_boun
                      const double org[3], const double dir[3], rtmo_rng_fn rng, void* rng_ctx,
                      double out_radiance[3], rtmo_counters* counters);
 
+/* Same, drawing from the build RNG stream (seed, pixel, sample) — what rtm_path_trace_batch uses */
+void rtmo_path_trace_stream(const rtm_sphere* spheres, size_t n, int mode, int max_bounces,
+                            const double org[3], const double dir[3], uint64_t seed,
+                            uint32_t pixel, uint32_t sample, double out_radiance[3],
+                            rtmo_counters* counters);
+
 /* src/Renderer.cpp:202-208 */
 void rtmo_camera_basis(const rtm_settings* st, double cam_x[3], double cam_y[3], double cam_z[3],
                        double* fovx, double* fovy);

@@ -1,0 +1,104 @@
+// rtm_api.cpp — the extern "C" surface of include/rtm.h.  Thin: argument checks live with the
+// implementations; no exception crosses the ABI.
+#include <exception>
+
+#include "rtm_internal.h"
+
+#define RTM_GUARD(call)                                  \
+    try {                                                \
+        return (call);                                   \
+    } catch (const std::exception& e) {                  \
+        rtm::set_last_error(e.what());                   \
+        return RTM_ERR_INVALID_ARGUMENT;                 \
+    } catch (...) {                                      \
+        rtm::set_last_error("unknown exception");        \
+        return RTM_ERR_INVALID_ARGUMENT;                 \
+    }
+
+extern "C" {
+
+int rtm_abi_version(void) { return RTM_ABI_VERSION; }
+
+const char* rtm_strerror(int status) {
+    switch (status) {
+        case RTM_OK: return "ok";
+        case RTM_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case RTM_ERR_INVALID_SCENE: return "invalid scene";
+        case RTM_ERR_IO: return "i/o error";
+        case RTM_ERR_PARSE: return "json parse error";
+        case RTM_ERR_NO_DEVICE: return "no HIP device";
+        case RTM_ERR_HIP: return "HIP runtime error";
+        case RTM_ERR_CAPACITY: return "buffer too small";
+        case RTM_ERR_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown status";
+}
+const char* rtm_last_error_detail(void) { return rtm::last_error(); }
+int rtm_device_count(int* count) { RTM_GUARD(rtm::device_count(count)) }
+int rtm_num_variants(void) { return rtm::num_variants(); }
+const char* rtm_variant_name(int variant) { return rtm::variant_name(variant); }
+
+int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
+                      int spheres_on_device, const rtm_options* options, double* out_f64_dev,
+                      float* out_f32_dev, uint8_t* out_u8_dev, void* stream, rtm_stats* stats) {
+    RTM_GUARD(rtm::render_device(settings, spheres, n_spheres, spheres_on_device, options,
+                                 out_f64_dev, out_f32_dev, out_u8_dev, stream, stats))
+}
+int rtm_render(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
+               const rtm_options* options, double* out_f64, float* out_f32, uint8_t* out_u8,
+               rtm_stats* stats) {
+    RTM_GUARD(rtm::render_host(settings, spheres, n_spheres, options, out_f64, out_f32, out_u8, stats))
+}
+int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options,
+                         const double* org, const double* dir, size_t n_rays, double* out_radiance,
+                         uint32_t* out_draws, uint32_t* out_casts) {
+    RTM_GUARD(rtm::path_trace_batch(spheres, n_spheres, options, org, dir, n_rays, out_radiance,
+                                    out_draws, out_casts))
+}
+int rtm_intersect_batch(const rtm_sphere* spheres, const double* org, const double* dir, size_t n,
+                        int mode, int32_t* out_hit, double* out_t, double* out_normal) {
+    RTM_GUARD(rtm::intersect_batch(spheres, org, dir, n, mode, out_hit, out_t, out_normal))
+}
+double rtm_rng_u01(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index) {
+    return rtm::rng_u01_host(seed, pixel, sample, index);
+}
+int rtm_rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample,
+                  uint32_t n_draws, double* out) {
+    RTM_GUARD(rtm::rng_batch(seed, pixel0, n_pixels, sample, n_draws, out))
+}
+/* test hook, not part of the documented ABI: device sqrt/sqrtf/div/sin/cos on caller data */
+int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, double* out) {
+    RTM_GUARD(rtm::math_probe(op, a, b, n, out))
+}
+
+int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,
+                        rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
+    RTM_GUARD(rtm::scene_load_json(path, literal_loader, settings, spheres, capacity, n_spheres))
+}
+int rtm_scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* settings,
+                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
+    RTM_GUARD(rtm::scene_parse_json(text, len, literal_loader, settings, spheres, capacity, n_spheres))
+}
+int rtm_scene_save_sample_json(const char* path) { RTM_GUARD(rtm::scene_save_sample_json(path)) }
+int rtm_scene_make_stress(uint64_t seed, size_t n, rtm_settings* settings, rtm_sphere* spheres) {
+    RTM_GUARD(rtm::scene_make_stress(seed, n, settings, spheres))
+}
+int rtm_quantise(const double* image, size_t n_values, uint8_t* out) {
+    RTM_GUARD(rtm::quantise(image, n_values, out))
+}
+int rtm_write_bmp(const char* filename, int w, int h, int comp, const void* data) {
+    try {
+        return rtm::write_bmp(filename, w, h, comp, data);
+    } catch (...) {
+        return 0;
+    }
+}
+int rtm_write_jpg(const char* filename, int w, int h, int comp, const void* data, int quality) {
+    try {
+        return rtm::write_jpg(filename, w, h, comp, data, quality);
+    } catch (...) {
+        return 0;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// rtm_internal.h — C++ entry points behind the C ABI (include/rtm.h).  Not installed.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/rtm.h"
+
+namespace rtm {
+
+void set_last_error(const std::string& s);
+const char* last_error();
+
+// device path (rtm_kernels.hip)
+int device_count(int* count);
+int num_variants();
+const char* variant_name(int v);
+int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int spheres_on_device,
+                  const rtm_options* opt, double* out64, float* out32, uint8_t* out8, void* stream,
+                  rtm_stats* stats);
+int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt,
+                double* out64, float* out32, uint8_t* out8, rtm_stats* stats);
+int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,
+                     const double* dir, size_t n_rays, double* out, uint32_t* out_draws,
+                     uint32_t* out_casts);
+int intersect_batch(const rtm_sphere* sp, const double* org, const double* dir, size_t n, int mode,
+                    int32_t* out_hit, double* out_t, double* out_normal);
+int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample, uint32_t n_draws,
+              double* out);
+double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index);
+int math_probe(int op, const double* a, const double* b, size_t n, double* out);
+
+// host side (rtm_scene.cpp, rtm_image.cpp)
+int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* st,
+                     rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
+int scene_load_json(const char* path, int literal_loader, rtm_settings* st, rtm_sphere* spheres,
+                    size_t capacity, size_t* n_spheres);
+int scene_save_sample_json(const char* path);
+int scene_make_stress(uint64_t seed, size_t n, rtm_settings* st, rtm_sphere* spheres);
+int quantise(const double* image, size_t n_values, uint8_t* out);
+int write_bmp(const char* filename, int w, int h, int comp, const void* data);
+int write_jpg(const char* filename, int w, int h, int comp, const void* data, int quality);
+
+}  // namespace rtm

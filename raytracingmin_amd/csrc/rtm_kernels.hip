@@ -1,0 +1,807 @@
+// rtm_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) for the RaytracingMin hot path and
+// the device half of the C ABI in include/rtm.h.
+//
+// Path (reference file:line): Renderer::Render's pixel/sample loop src/Renderer.cpp:215-250,
+// png::PathTracing src/Renderer.cpp:57-117, SphereObject::Intersect src/SettingData.cpp:197-226,
+// vec3 math src/Ray.h:7-72, Material src/SettingData.h:8-17.
+//
+// Shape of the render kernel:
+//   * one 64-lane wavefront owns one 8x8 pixel tile, one lane per pixel; a lane walks its pixel's
+//     SS*SS*S samples in the reference's order (sx, sy, s) so the fp64 accumulation order is the
+//     reference's.
+//   * the per-sample recursion is flattened into one loop of ray casts with path regeneration: a
+//     lane whose path ended folds it, accumulates, and starts its next sample in the same
+//     iteration, so every live lane casts a ray on every iteration (no bounce-depth idling).
+//   * per-bounce hit records (the object index of every continued bounce) are staged in LDS,
+//     [depth][lane]; the radiance is folded back-to-front from them so the arithmetic order is
+//     the recursion's (L = colorKD * L_next + emission, src/Renderer.cpp:109).
+//   * the scene is brute-forced in index order (strict <, lowest index wins ties); sphere geometry
+//     is read with wave-uniform (scalar) loads, materials are gathered per lane.
+//   * no MFMA: there is no dense contraction on this path.  fp64 throughout, float islands kept.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtm.h"
+#include "rtm_device.h"
+#include "rtm_internal.h"
+
+namespace rtm {
+
+// ------------------------------------------------------------------------------------------------
+// Scene as the kernels see it.  geom[i] = (cx, cy, cz, (double)(float)(r*r)): 32 B per sphere.
+// mat[i*8 + 0..7] = colorKD.xyz, kd (float widened), emission.xyz, pad: 64 B per sphere.
+struct SceneView {
+    const double4* __restrict__ geom;
+    const double* __restrict__ mat;
+    int n;
+};
+
+struct RenderParams {
+    SceneView scene;
+    int W, H, S, SS;
+    int row_begin, row_end;
+    int tiles_x;
+    int mode, max_bounces;
+    unsigned total_samples;  // SS*SS*S per pixel
+    float rate;              // 1.0 / (1 + SS) as float, src/Renderer.cpp:227
+    double dSS, dS;          // divisors of src/Renderer.cpp:240
+    D3 cam_org, ax, by, cz;  // origin, camX*fovx, camY*fovy, camZ (src/Renderer.cpp:202-208)
+    uint64_t seed_mult;
+    double* __restrict__ out64;
+    float* __restrict__ out32;
+    uint8_t* __restrict__ out8;
+    unsigned long long* __restrict__ counters;  // casts, bounces, draws, overflow flag
+};
+
+// src/SettingData.cpp:197-226 without the normal: returns hit and t.
+__device__ __forceinline__ bool sphere_test(const double4 g, const D3 org, const D3 dir,
+                                            double& t) {
+    const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // :198
+    const double b = dot(p_o, dir);                            // :199
+    const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200 (g.w = float r*r widened)
+    if (D4 < 0.0) return false;                                // :202
+    const double sq = sqrt(D4);                                // :205
+    const double t1 = b - sq, t2 = b + sq;
+    const double min_value = (double)1e-5f;                    // :208
+    if (t1 < min_value && t2 < min_value) return false;        // :209
+    t = (t1 > 0.001) ? t1 : t2;                                // :212-223
+    return true;
+}
+// src/SettingData.cpp:214-215: out_normal = Normalize(hitPoint - m_position)
+__device__ __forceinline__ D3 sphere_normal(const double4 g, const D3 hit_point) {
+    return normalize(hit_point - d3(g.x, g.y, g.z));
+}
+
+// src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
+__device__ __forceinline__ int nearest_hit(const SceneView& sc, const D3 org, const D3 dir,
+                                           double& dis) {
+    int hit_object = -1;
+    dis = DBL_MAX;
+    for (int i = 0; i < sc.n; ++i) {
+        const double4 g = sc.geom[i];  // wave-uniform address
+        double t;
+        if (sphere_test(g, org, dir, t) && t < dis && t > 0) {
+            dis = t;
+            hit_object = i;
+        }
+    }
+    return hit_object;
+}
+
+struct PathCounters {
+    unsigned casts, bounces, draws;
+};
+
+// One PathTracing invocation (src/Renderer.cpp:57-117) on the flattened path.
+// Returns true when the path continues (org/dir/depth updated, hit id pushed through `push`);
+// false when it ended with `term` = the value the deepest invocation returned.
+template <typename PushFn>
+__device__ __forceinline__ bool path_step(const SceneView& sc, const int mode,
+                                          const int max_bounces, D3& org, D3& dir, int& depth,
+                                          RngStream& rng, D3& term, PathCounters& pc,
+                                          PushFn push) {
+    double dis;
+    const int id = nearest_hit(sc, org, dir, dis);
+    pc.casts++;
+    if (id < 0) {  // :116
+        term = d3(0, 0, 0);
+        return false;
+    }
+    const double* m = sc.mat + (size_t)id * 8;
+    const D3 emission = d3(m[4], m[5], m[6]);
+    if (max_bounces >= 0 && depth >= max_bounces) {  // build extension: no draw
+        term = emission;
+        return false;
+    }
+    pc.draws++;
+    if (!(rng_next(rng) <= m[3])) {  // :78, kd() is a float widened to double
+        term = emission;             // :112
+        return false;
+    }
+    const D3 hit_point = dir * dis + org;  // :79
+    // D2: in literal mode the caller's normal stays (0,0,0)
+    const D3 normal =
+        (mode == RTM_MODE_LITERAL) ? d3(0, 0, 0) : sphere_normal(sc.geom[id], hit_point);
+    const D3 w = dot(normal, dir) < 0.0 ? normal : normal * -1.0;  // :82-83
+    pc.draws += 2;
+    const double r1 = 6.283185307179586 * rng_next(rng);  // :88  (2*PI folded)
+    const double r2 = rng_next(rng);                      // :89
+    const double r2s = sqrt(r2);                          // :90
+    D3 u;
+    if (fabs(w.x) > (double)FLT_MIN)  // :96
+        u = normalize(cross(d3(0, 1, 0), w));
+    else
+        u = normalize(cross(d3(1, 0, 0), w));
+    const D3 v = cross(w, u);  // :102
+    double sn, cs;
+    sincos(r1, &sn, &cs);
+    const D3 nd = normalize((u * cs) * r2s + (v * sn) * r2s + w * sqrt(1.0 - r2));  // :103-107
+    push(depth, id);
+    depth++;
+    pc.bounces++;
+    org = hit_point;
+    dir = nd;
+    return true;
+}
+
+// Fold the recursion back to front: L = colorKD * L_next + emission (src/Renderer.cpp:109).
+template <typename PopFn>
+__device__ __forceinline__ D3 path_fold(const SceneView& sc, const D3 term, const int depth,
+                                        PopFn pop) {
+    D3 L = term;
+    for (int d = depth - 1; d >= 0; --d) {
+        const double* m = sc.mat + (size_t)pop(d) * 8;
+        L = d3(m[0], m[1], m[2]) * L + d3(m[4], m[5], m[6]);
+    }
+    return L;
+}
+
+// src/Renderer.cpp:43-49: std::min<double>(std::max<double>(v, 0), 1.0f)
+__device__ __forceinline__ double clamp01(double v) {
+    const double lo = (v < 0.0) ? 0.0 : v;
+    return (1.0 < lo) ? 1.0 : lo;
+}
+
+// src/Renderer.cpp:227-232; sx, sy in 1..SS
+__device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
+    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
+    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
+    return normalize((P.ax * px + P.by * py) + P.cz);
+}
+
+__device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsigned v) {
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The render kernel.  RecT: hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged
+// in LDS per lane.
+template <typename RecT, int LDS_D>
+__global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) {
+    __shared__ RecT rec[LDS_D * 64];
+    const int lane = threadIdx.x;
+    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int y = P.row_begin + ty * 8 + (lane >> 3);
+    const bool valid = (x < P.W) && (y < P.row_end);
+    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;  // GLOBAL pixel index
+
+    const SceneView sc = P.scene;
+    PathCounters pc = {0, 0, 0};
+    bool overflow = false;
+    D3 acc = d3(0, 0, 0);
+
+    unsigned n = valid ? 0u : P.total_samples;  // sample index ((sx-1)*SS + (sy-1))*S + s
+    int s_in_sub = 0, sub = 0;
+    D3 pdir = primary_dir(P, x, y, 1, 1);
+    D3 org = P.cam_org, dir = pdir;
+    int depth = 0;
+    RngStream rng = rng_open(P.seed_mult, pixel, 0u);
+
+    auto push = [&](int d, int id) {
+        if (d < LDS_D)
+            rec[d * 64 + lane] = (RecT)id;
+        else
+            overflow = true;
+    };
+    auto pop = [&](int d) -> int { return (int)rec[(d < LDS_D ? d : LDS_D - 1) * 64 + lane]; };
+
+    while (n < P.total_samples) {
+        D3 term;
+        bool cont = path_step(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
+        if (cont && depth > LDS_D) {  // records exhausted: stop the path, flag it (loud failure)
+            cont = false;
+            term = d3(0, 0, 0);
+            depth = LDS_D;
+        }
+        if (!cont) {
+            const D3 L = path_fold(sc, term, depth, pop);
+            D3 cal = ((L / P.dSS) / P.dSS) / P.dS;  // :240
+            acc = acc + d3(clamp01(cal.x), clamp01(cal.y), clamp01(cal.z));  // :241-242
+            ++n;
+            if (++s_in_sub == P.S) {
+                s_in_sub = 0;
+                ++sub;
+                if (n < P.total_samples) pdir = primary_dir(P, x, y, sub / P.SS + 1, sub % P.SS + 1);
+            }
+            org = P.cam_org;
+            dir = pdir;
+            depth = 0;
+            rng = rng_open(P.seed_mult, pixel, n);
+        }
+    }
+
+    if (valid) {
+        const size_t o = ((size_t)(y - P.row_begin) * P.W + x) * 3;
+        const double r = 0.0 + acc.x, g = 0.0 + acc.y, b = 0.0 + acc.z;  // :246-248
+        if (P.out64) {
+            P.out64[o] = r;
+            P.out64[o + 1] = g;
+            P.out64[o + 2] = b;
+        }
+        if (P.out32) {
+            P.out32[o] = (float)r;
+            P.out32[o + 1] = (float)g;
+            P.out32[o + 2] = (float)b;
+        }
+        if (P.out8) {  // :253: (unsigned char)255 * std::min(v, 1.0), truncation
+            const double q[3] = {r, g, b};
+            for (int c = 0; c < 3; ++c) {
+                const double v = 255 * ((1.0 < q[c]) ? 1.0 : q[c]);
+                P.out8[o + c] = (v >= 0.0 && v < 256.0) ? (uint8_t)v : (uint8_t)0;
+            }
+        }
+    }
+    if (P.counters) {
+        wave_add_counter(P.counters + 0, pc.casts);
+        wave_add_counter(P.counters + 1, pc.bounces);
+        wave_add_counter(P.counters + 2, pc.draws);
+        if (overflow) atomicOr(P.counters + 3, 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-ray seam: png::PathTracing for a batch of rays (one lane per ray).
+struct RayBatchParams {
+    SceneView scene;
+    int mode, max_bounces;
+    uint64_t seed_mult;
+    const double* __restrict__ org;
+    const double* __restrict__ dir;
+    size_t n_rays;
+    double* __restrict__ out;
+    uint32_t* __restrict__ out_draws;
+    uint32_t* __restrict__ out_casts;
+    uint32_t* __restrict__ scratch;  // [depth][ray] hit records, RAY_MAX_DEPTH deep
+    unsigned long long* __restrict__ counters;
+};
+constexpr int RAY_MAX_DEPTH = 4096;
+
+__global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParams P) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= P.n_rays) return;
+    D3 org = d3(P.org[i * 3], P.org[i * 3 + 1], P.org[i * 3 + 2]);
+    D3 dir = d3(P.dir[i * 3], P.dir[i * 3 + 1], P.dir[i * 3 + 2]);
+    RngStream rng = rng_open(P.seed_mult, (uint32_t)i, 0u);
+    PathCounters pc = {0, 0, 0};
+    int depth = 0;
+    bool overflow = false;
+    auto push = [&](int d, int id) {
+        if (d < RAY_MAX_DEPTH)
+            P.scratch[(size_t)d * P.n_rays + i] = (uint32_t)id;
+        else
+            overflow = true;
+    };
+    auto pop = [&](int d) -> int { return (int)P.scratch[(size_t)d * P.n_rays + i]; };
+    D3 term;
+    while (path_step(P.scene, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push)) {
+        if (depth >= RAY_MAX_DEPTH) {
+            overflow = true;
+            term = d3(0, 0, 0);
+            break;
+        }
+    }
+    const D3 L = path_fold(P.scene, term, depth, pop);
+    P.out[i * 3] = L.x;
+    P.out[i * 3 + 1] = L.y;
+    P.out[i * 3 + 2] = L.z;
+    if (P.out_draws) P.out_draws[i] = pc.draws;
+    if (P.out_casts) P.out_casts[i] = pc.casts;
+    if (overflow) atomicOr(P.counters + 3, 1ull);
+}
+
+// Per-call seam: SphereObject::Intersect, pair i = (ray i, sphere i).
+__global__ __launch_bounds__(64) void intersect_pairs_kernel(const double4* __restrict__ geom,
+                                                             const double* __restrict__ org,
+                                                             const double* __restrict__ dir,
+                                                             size_t n, int mode,
+                                                             int32_t* __restrict__ out_hit,
+                                                             double* __restrict__ out_t,
+                                                             double* __restrict__ out_normal) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const D3 o = d3(org[i * 3], org[i * 3 + 1], org[i * 3 + 2]);
+    const D3 d = d3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
+    const double4 g = geom[i];
+    double t;
+    const bool hit = sphere_test(g, o, d, t);
+    out_hit[i] = hit ? 1 : 0;
+    if (hit) {
+        out_t[i] = t;
+        if (mode != RTM_MODE_LITERAL) {  // D2: literal mode never delivers the normal
+            const D3 nrm = sphere_normal(g, o + d * t);
+            out_normal[i * 3] = nrm.x;
+            out_normal[i * 3 + 1] = nrm.y;
+            out_normal[i * 3 + 2] = nrm.z;
+        }
+    }
+}
+
+__global__ void rng_batch_kernel(uint64_t seed_mult, uint32_t pixel0, uint32_t n_pixels,
+                                 uint32_t sample, uint32_t n_draws, double* __restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    RngStream s = rng_open(seed_mult, pixel0 + p, sample);
+    for (uint32_t k = 0; k < n_draws; ++k) out[(size_t)p * n_draws + k] = rng_next(s);
+}
+
+// Device primitives exposed for parity tests of the building blocks (tests/test_device_math.py).
+__global__ void math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
+                                  size_t n, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0;
+    double r = 0.0, s, c;
+    switch (op) {
+        case 0: r = sqrt(x); break;
+        case 1: r = (double)__builtin_sqrtf((float)x); break;
+        case 2: r = x / y; break;
+        case 3: r = sin(x); break;
+        case 4: r = cos(x); break;
+        case 5: sincos(x, &s, &c); r = s; break;
+        case 6: sincos(x, &s, &c); r = c; break;
+        case 7: r = x * y + 1.0; break;  // must NOT be contracted to an fma
+    }
+    out[i] = r;
+}
+
+// ================================================================================================
+// Host side of the device path
+// ================================================================================================
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+const char* last_error() { return g_last_error.c_str(); }
+
+#define RTM_HIP_CHECK(expr)                                                               \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
+            return RTM_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+// src/Ray.h / src/Renderer.cpp:202-208 on the host, same operation order as the device code
+namespace host {
+struct H3 {
+    double x, y, z;
+};
+static H3 sub(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static H3 cross(H3 a, H3 b) {
+    return {a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x};
+}
+static H3 normalize(H3 a) {
+    const float len2 = (float)(a.x * a.x + a.y * a.y + a.z * a.z);
+    const double m = (double)sqrtf(len2);
+    return {a.x / m, a.y / m, a.z / m};
+}
+}  // namespace host
+
+// Flatten rtm_sphere[] to the kernel layout.  kd and colorKD are hoisted: the same
+// IEEE operations the reference redoes per bounce (src/SettingData.h:11-16).
+static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& geom,
+                          std::vector<double>& mat) {
+    geom.resize(n * 4);
+    mat.resize(n * 8);
+    for (size_t i = 0; i < n; ++i) {
+        const float r2 = sp[i].radius * sp[i].radius;  // float product, src/SettingData.cpp:200
+        geom[i * 4 + 0] = sp[i].center[0];
+        geom[i * 4 + 1] = sp[i].center[1];
+        geom[i * 4 + 2] = sp[i].center[2];
+        geom[i * 4 + 3] = (double)r2;
+        double m = sp[i].color[0] < sp[i].color[1] ? sp[i].color[1] : sp[i].color[0];
+        m = m < sp[i].color[2] ? sp[i].color[2] : m;
+        const double kd = (double)(float)m;  // kd() returns float
+        mat[i * 8 + 0] = sp[i].color[0] / kd;
+        mat[i * 8 + 1] = sp[i].color[1] / kd;
+        mat[i * 8 + 2] = sp[i].color[2] / kd;
+        mat[i * 8 + 3] = kd;
+        mat[i * 8 + 4] = sp[i].emission[0];
+        mat[i * 8 + 5] = sp[i].emission[1];
+        mat[i * 8 + 6] = sp[i].emission[2];
+        mat[i * 8 + 7] = 0.0;
+    }
+}
+
+__global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n,
+                                     double* __restrict__ geom, double* __restrict__ mat) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r2 = sp[i].radius * sp[i].radius;
+    geom[i * 4 + 0] = sp[i].center[0];
+    geom[i * 4 + 1] = sp[i].center[1];
+    geom[i * 4 + 2] = sp[i].center[2];
+    geom[i * 4 + 3] = (double)r2;
+    double m = sp[i].color[0] < sp[i].color[1] ? sp[i].color[1] : sp[i].color[0];
+    m = m < sp[i].color[2] ? sp[i].color[2] : m;
+    const double kd = (double)(float)m;
+    mat[i * 8 + 0] = sp[i].color[0] / kd;
+    mat[i * 8 + 1] = sp[i].color[1] / kd;
+    mat[i * 8 + 2] = sp[i].color[2] / kd;
+    mat[i * 8 + 3] = kd;
+    mat[i * 8 + 4] = sp[i].emission[0];
+    mat[i * 8 + 5] = sp[i].emission[1];
+    mat[i * 8 + 6] = sp[i].emission[2];
+    mat[i * 8 + 7] = 0.0;
+}
+
+// Scene buffers on the device for the lifetime of one call (stream-ordered).
+struct DeviceScene {
+    double* geom = nullptr;
+    double* mat = nullptr;
+    unsigned long long* counters = nullptr;
+    hipStream_t stream = nullptr;
+    int upload(const rtm_sphere* sp, size_t n, int on_device, hipStream_t st) {
+        stream = st;
+        const size_t nn = n ? n : 1;
+        RTM_HIP_CHECK(hipMallocAsync((void**)&geom, nn * 4 * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMallocAsync((void**)&mat, nn * 8 * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMallocAsync((void**)&counters, 4 * sizeof(unsigned long long), stream));
+        RTM_HIP_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), stream));
+        if (n == 0) return RTM_OK;
+        if (on_device) {
+            flatten_scene_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(sp, n, geom, mat);
+            RTM_HIP_CHECK(hipGetLastError());
+        } else {
+            std::vector<double> hg, hm;
+            flatten_scene(sp, n, hg, hm);
+            // pageable source: the copy is staged before the call returns
+            RTM_HIP_CHECK(hipMemcpyAsync(geom, hg.data(), hg.size() * sizeof(double),
+                                         hipMemcpyHostToDevice, stream));
+            RTM_HIP_CHECK(hipMemcpyAsync(mat, hm.data(), hm.size() * sizeof(double),
+                                         hipMemcpyHostToDevice, stream));
+            RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        return RTM_OK;
+    }
+    void release() {
+        if (geom) (void)hipFreeAsync(geom, stream);
+        if (mat) (void)hipFreeAsync(mat, stream);
+        if (counters) (void)hipFreeAsync(counters, stream);
+        geom = mat = nullptr;
+        counters = nullptr;
+    }
+    ~DeviceScene() { release(); }
+};
+
+static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt) {
+    if (!st || !opt || (!sp && n)) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (st->width <= 0 || st->height <= 0 || st->samples <= 0 || st->super_samples <= 0) {
+        set_last_error("width, height, samples and superSamples must be positive");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->row_begin < 0 || opt->row_end > st->height || opt->row_begin > opt->row_end) {
+        set_last_error("row range outside the image");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {
+        set_last_error("unknown mode");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if ((uint64_t)st->super_samples * st->super_samples * st->samples > 0xFFFFFFFFull ||
+        (uint64_t)st->width * st->height > 0xFFFFFFFFull || n > 0x7FFFFFFFull) {
+        set_last_error("image, sample or scene count exceeds 32-bit indexing");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    if (opt->variant < 0 || opt->variant >= num_variants()) {
+        set_last_error("unknown kernel variant");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    return RTM_OK;
+}
+
+static const char* kVariantNames[] = {"tile8x8-regen-lds"};
+int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
+const char* variant_name(int v) { return (v >= 0 && v < num_variants()) ? kVariantNames[v] : nullptr; }
+
+static void fill_render_params(RenderParams& P, const rtm_settings* st, const rtm_options* opt) {
+    using namespace host;
+    const H3 origin = {st->camera.origin[0], st->camera.origin[1], st->camera.origin[2]};
+    const H3 target = {st->camera.target[0], st->camera.target[1], st->camera.target[2]};
+    const H3 up = {st->camera.up[0], st->camera.up[1], st->camera.up[2]};
+    const H3 direction = normalize(sub(target, origin));  // src/Renderer.cpp:202
+    const H3 c0 = normalize(cross(direction, up));        // :203
+    const H3 cam_x = {-c0.x, -c0.y, -c0.z};
+    const H3 cam_y = cross(cam_x, direction);  // :204
+    const double fovx = (double)st->camera.fov;
+    const double fovy = fovx * st->height / st->width;  // :208
+    P.W = st->width;
+    P.H = st->height;
+    P.S = st->samples;
+    P.SS = st->super_samples;
+    P.row_begin = opt->row_begin;
+    P.row_end = opt->row_end;
+    P.tiles_x = (st->width + 7) / 8;
+    P.mode = opt->mode;
+    P.max_bounces = opt->max_bounces;
+    P.total_samples = (unsigned)st->super_samples * st->super_samples * st->samples;
+    P.rate = (float)(1.0 / (1 + st->super_samples));
+    P.dSS = (double)st->super_samples;
+    P.dS = (double)st->samples;
+    P.cam_org = D3{origin.x, origin.y, origin.z};
+    P.ax = D3{cam_x.x * fovx, cam_x.y * fovx, cam_x.z * fovx};  // l_camX * fovx, :229
+    P.by = D3{cam_y.x * fovy, cam_y.y * fovy, cam_y.z * fovy};  // l_camY * fovy, :230
+    P.cz = D3{direction.x, direction.y, direction.z};
+    P.seed_mult = seed_multiplier(opt->seed);
+}
+
+template <typename RecT>
+static void launch_render(const RenderParams& P, unsigned grid, hipStream_t stream) {
+    if (P.max_bounces >= 0 && P.max_bounces < 16)
+        render_tiles_kernel<RecT, 16><<<grid, 64, 0, stream>>>(P);
+    else if (sizeof(RecT) == 1)
+        render_tiles_kernel<RecT, 128><<<grid, 64, 0, stream>>>(P);
+    else
+        render_tiles_kernel<RecT, 64><<<grid, 64, 0, stream>>>(P);
+}
+
+int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
+                  const rtm_options* opt, double* out64, float* out32, uint8_t* out8,
+                  void* stream_v, rtm_stats* stats) {
+    int rc = validate(st, sp, n, opt);
+    if (rc != RTM_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    RTM_HIP_CHECK(hipSetDevice(opt->device));
+    const int rows = opt->row_end - opt->row_begin;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (rows == 0) return RTM_OK;
+
+    DeviceScene ds;
+    rc = ds.upload(sp, n, on_device, stream);
+    if (rc != RTM_OK) return rc;
+
+    RenderParams P;
+    std::memset(&P, 0, sizeof P);
+    fill_render_params(P, st, opt);
+    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    P.out64 = out64;
+    P.out32 = out32;
+    P.out8 = out8;
+    P.counters = ds.counters;
+    const unsigned tiles_y = (unsigned)((rows + 7) / 8);
+    const unsigned grid = (unsigned)P.tiles_x * tiles_y;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        RTM_HIP_CHECK(hipEventCreate(&ev0));
+        RTM_HIP_CHECK(hipEventCreate(&ev1));
+        RTM_HIP_CHECK(hipEventRecord(ev0, stream));
+    }
+    if (n <= 256)
+        launch_render<uint8_t>(P, grid, stream);
+    else
+        launch_render<uint32_t>(P, grid, stream);
+    RTM_HIP_CHECK(hipGetLastError());
+    if (stats) {
+        RTM_HIP_CHECK(hipEventRecord(ev1, stream));
+        unsigned long long c[4];
+        RTM_HIP_CHECK(hipMemcpyAsync(c, ds.counters, sizeof c, hipMemcpyDeviceToHost, stream));
+        RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        RTM_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
+        stats->samples = (uint64_t)rows * st->width * P.total_samples;
+        stats->casts = c[0];
+        stats->bounces = c[1];
+        stats->draws = c[2];
+        stats->kernel_ms = ms;
+        if (c[3]) {
+            set_last_error("a path ran deeper than the hit-record capacity of this kernel");
+            return RTM_ERR_UNSUPPORTED;
+        }
+    }
+    return RTM_OK;
+}
+
+int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt,
+                double* out64, float* out32, uint8_t* out8, rtm_stats* stats) {
+    int rc = validate(st, sp, n, opt);
+    if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipSetDevice(opt->device));
+    const size_t vals = (size_t)(opt->row_end - opt->row_begin) * st->width * 3;
+    double* d64 = nullptr;
+    float* d32 = nullptr;
+    uint8_t* d8 = nullptr;
+    rtm_stats local;
+    if (vals) {
+        if (out64) RTM_HIP_CHECK(hipMalloc((void**)&d64, vals * sizeof(double)));
+        if (out32) RTM_HIP_CHECK(hipMalloc((void**)&d32, vals * sizeof(float)));
+        if (out8) RTM_HIP_CHECK(hipMalloc((void**)&d8, vals));
+    }
+    rc = render_device(st, sp, n, 0, opt, d64, d32, d8, nullptr, &local);
+    if (rc == RTM_OK && vals) {
+        if (out64) RTM_HIP_CHECK(hipMemcpy(out64, d64, vals * sizeof(double), hipMemcpyDeviceToHost));
+        if (out32) RTM_HIP_CHECK(hipMemcpy(out32, d32, vals * sizeof(float), hipMemcpyDeviceToHost));
+        if (out8) RTM_HIP_CHECK(hipMemcpy(out8, d8, vals, hipMemcpyDeviceToHost));
+    }
+    if (d64) (void)hipFree(d64);
+    if (d32) (void)hipFree(d32);
+    if (d8) (void)hipFree(d8);
+    if (stats) *stats = local;
+    return rc;
+}
+
+int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,
+                     const double* dir, size_t n_rays, double* out, uint32_t* out_draws,
+                     uint32_t* out_casts) {
+    if (!opt || (!sp && n) || !org || !dir || !out) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {
+        set_last_error("unknown mode");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (n_rays == 0) return RTM_OK;
+    RTM_HIP_CHECK(hipSetDevice(opt->device));
+    DeviceScene ds;
+    int rc = ds.upload(sp, n, 0, nullptr);
+    if (rc != RTM_OK) return rc;
+    double *d_org = nullptr, *d_dir = nullptr, *d_out = nullptr;
+    uint32_t *d_draws = nullptr, *d_casts = nullptr, *d_scratch = nullptr;
+    const size_t vb = n_rays * 3 * sizeof(double);
+    RTM_HIP_CHECK(hipMalloc((void**)&d_org, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_dir, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_out, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_draws, n_rays * 4));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_casts, n_rays * 4));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_scratch, (size_t)RAY_MAX_DEPTH * n_rays * 4));
+    RTM_HIP_CHECK(hipMemcpy(d_org, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir, dir, vb, hipMemcpyHostToDevice));
+    RayBatchParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    P.mode = opt->mode;
+    P.max_bounces = opt->max_bounces;
+    P.seed_mult = seed_multiplier(opt->seed);
+    P.org = d_org;
+    P.dir = d_dir;
+    P.n_rays = n_rays;
+    P.out = d_out;
+    P.out_draws = d_draws;
+    P.out_casts = d_casts;
+    P.scratch = d_scratch;
+    P.counters = ds.counters;
+    path_trace_rays_kernel<<<(unsigned)((n_rays + 63) / 64), 64>>>(P);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long c[4];
+    RTM_HIP_CHECK(hipMemcpy(c, ds.counters, sizeof c, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out, d_out, vb, hipMemcpyDeviceToHost));
+    if (out_draws) RTM_HIP_CHECK(hipMemcpy(out_draws, d_draws, n_rays * 4, hipMemcpyDeviceToHost));
+    if (out_casts) RTM_HIP_CHECK(hipMemcpy(out_casts, d_casts, n_rays * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(d_org);
+    (void)hipFree(d_dir);
+    (void)hipFree(d_out);
+    (void)hipFree(d_draws);
+    (void)hipFree(d_casts);
+    (void)hipFree(d_scratch);
+    if (c[3]) {
+        set_last_error("a path ran deeper than RAY_MAX_DEPTH");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    return RTM_OK;
+}
+
+int intersect_batch(const rtm_sphere* sp, const double* org, const double* dir, size_t n, int mode,
+                    int32_t* out_hit, double* out_t, double* out_normal) {
+    if (!sp || !org || !dir || !out_hit || !out_t || !out_normal) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return RTM_OK;
+    DeviceScene ds;
+    int rc = ds.upload(sp, n, 0, nullptr);
+    if (rc != RTM_OK) return rc;
+    double *d_org, *d_dir, *d_t, *d_n;
+    int32_t* d_hit;
+    const size_t vb = n * 3 * sizeof(double);
+    RTM_HIP_CHECK(hipMalloc((void**)&d_org, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_dir, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_n, vb));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_t, n * sizeof(double)));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_hit, n * sizeof(int32_t)));
+    RTM_HIP_CHECK(hipMemcpy(d_org, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir, dir, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_n, out_normal, vb, hipMemcpyHostToDevice));  // untouched where no hit
+    RTM_HIP_CHECK(hipMemcpy(d_t, out_t, n * sizeof(double), hipMemcpyHostToDevice));
+    intersect_pairs_kernel<<<(unsigned)((n + 63) / 64), 64>>>((const double4*)ds.geom, d_org, d_dir,
+                                                              n, mode, d_hit, d_t, d_n);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipMemcpy(out_hit, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_t, d_t, n * sizeof(double), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_normal, d_n, vb, hipMemcpyDeviceToHost));
+    (void)hipFree(d_org);
+    (void)hipFree(d_dir);
+    (void)hipFree(d_n);
+    (void)hipFree(d_t);
+    (void)hipFree(d_hit);
+    return RTM_OK;
+}
+
+int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample, uint32_t n_draws,
+              double* out) {
+    if (!out) return RTM_ERR_INVALID_ARGUMENT;
+    const size_t total = (size_t)n_pixels * n_draws;
+    if (!total) return RTM_OK;
+    double* d;
+    RTM_HIP_CHECK(hipMalloc((void**)&d, total * sizeof(double)));
+    rng_batch_kernel<<<(n_pixels + 255) / 256, 256>>>(seed_multiplier(seed), pixel0, n_pixels, sample,
+                                                      n_draws, d);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipMemcpy(out, d, total * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return RTM_OK;
+}
+
+double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index) {
+    const RngStream s = rng_open(seed_multiplier(seed), pixel, sample);
+    return rng_u01_at(s.k0, s.k1, index);
+}
+
+int math_probe(int op, const double* a, const double* b, size_t n, double* out) {
+    if (!a || !out) return RTM_ERR_INVALID_ARGUMENT;
+    if (!n) return RTM_OK;
+    double *da, *db = nullptr, *dout;
+    RTM_HIP_CHECK(hipMalloc((void**)&da, n * 8));
+    RTM_HIP_CHECK(hipMalloc((void**)&dout, n * 8));
+    RTM_HIP_CHECK(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    if (b) {
+        RTM_HIP_CHECK(hipMalloc((void**)&db, n * 8));
+        RTM_HIP_CHECK(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+    }
+    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da, db, n, dout);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    return RTM_OK;
+}
+
+int device_count(int* count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        if (count) *count = 0;
+        set_last_error(std::string("no HIP device: ") + hipGetErrorString(e));
+        return RTM_ERR_NO_DEVICE;
+    }
+    if (count) *count = c;
+    return RTM_OK;
+}
+
+}  // namespace rtm

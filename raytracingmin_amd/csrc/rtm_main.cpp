@@ -1,0 +1,126 @@
+// rtm_main.cpp — host program: the reference's main() (src/main.cpp:8-46) on top of the C ABI.
+//
+//   rtm_cli [-?] [-json <file>] [-sampleJson]            (the reference's flags, same defaults)
+//           [--width N] [--height N] [--samples N] [--superSamples N] [--spp N]
+//           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM]
+//
+// Flow of the reference: pick the JSON (default settingData.json), create the sample JSON when it
+// does not exist, load, render, write <stem>.jpg (quality 60) and <stem>.bmp with stem "result".
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtm.h"
+
+static bool file_exists(const std::string& p) {
+    FILE* f = std::fopen(p.c_str(), "rb");
+    if (f) std::fclose(f);
+    return f != nullptr;
+}
+
+static void usage() {
+    std::printf(
+        "Usage: rtm_cli [OPTION]...\n\n"
+        "-sampleJson : save the sample scene json file as settingData.json\n"
+        "-json <file> : scene json file; settingData.json when not given\n"
+        "--width/--height/--samples/--superSamples N : override the file's values\n"
+        "--spp N : samples = N / superSamples^2\n"
+        "--mode literal|repaired (default repaired), --max-bounces N (default -1 = unlimited)\n"
+        "--seed N, --device N, --out STEM (default result)\n");
+}
+
+int main(int argc, char* argv[]) {
+    std::string json_file = "settingData.json", stem = "result";
+    int width = 0, height = 0, samples = 0, super_samples = 0, spp = 0;
+    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0;
+    unsigned long long seed = 0x5EED;
+    for (int i = 1; i < argc; ++i) {
+        const std::string c = argv[i];
+        auto next_int = [&](int& dst) {
+            if (i + 1 < argc) dst = std::atoi(argv[++i]);
+        };
+        if (c == "-?") {
+            usage();
+            return 0;
+        } else if (c == "-json") {  // src/main.cpp:18-28: falls back when the value is missing or a flag
+            if (argc <= i + 1 || argv[i + 1][0] == '-')
+                json_file = "settingData.json";
+            else
+                json_file = argv[++i];
+        } else if (c == "-sampleJson") {  // src/main.cpp:29-33
+            std::printf("saving the sample scene json file: settingData.json\n");
+            return rtm_scene_save_sample_json("settingData.json") == RTM_OK ? 0 : 1;
+        } else if (c == "--width") next_int(width);
+        else if (c == "--height") next_int(height);
+        else if (c == "--samples") next_int(samples);
+        else if (c == "--superSamples") next_int(super_samples);
+        else if (c == "--spp") next_int(spp);
+        else if (c == "--max-bounces") next_int(max_bounces);
+        else if (c == "--device") next_int(device);
+        else if (c == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
+        else if (c == "--out" && i + 1 < argc) stem = argv[++i];
+        else if (c == "--mode" && i + 1 < argc) {
+            const std::string m = argv[++i];
+            if (m == "literal") mode = RTM_MODE_LITERAL;
+            else if (m == "repaired") mode = RTM_MODE_REPAIRED;
+            else {
+                std::fprintf(stderr, "unknown mode %s\n", m.c_str());
+                return 2;
+            }
+        }
+    }
+    if (!file_exists(json_file)) {  // src/main.cpp:36-39
+        std::printf("saving the sample scene json file: %s\n", json_file.c_str());
+        if (rtm_scene_save_sample_json(json_file.c_str()) != RTM_OK) return 1;
+    }
+    std::printf("loading %s and starting the render\n", json_file.c_str());  // src/main.cpp:40
+
+    rtm_settings st;
+    size_t n = 0;
+    const int literal = (mode == RTM_MODE_LITERAL);
+    int rc = rtm_scene_load_json(json_file.c_str(), literal, &st, nullptr, 0, &n);
+    if (rc != RTM_OK) {
+        std::fprintf(stderr, "%s: %s (%s)\n", json_file.c_str(), rtm_strerror(rc), rtm_last_error_detail());
+        return 1;
+    }
+    std::vector<rtm_sphere> spheres(n ? n : 1);
+    rc = rtm_scene_load_json(json_file.c_str(), literal, &st, spheres.data(), n, &n);
+    if (rc != RTM_OK) {
+        std::fprintf(stderr, "%s: %s (%s)\n", json_file.c_str(), rtm_strerror(rc), rtm_last_error_detail());
+        return 1;
+    }
+    if (width > 0) st.width = width;
+    if (height > 0) st.height = height;
+    if (super_samples > 0) st.super_samples = super_samples;
+    if (samples > 0) st.samples = samples;
+    if (spp > 0) st.samples = spp / (st.super_samples * st.super_samples) > 0 ? spp / (st.super_samples * st.super_samples) : 1;
+
+    rtm_options opt;
+    std::memset(&opt, 0, sizeof opt);
+    opt.mode = mode;
+    opt.max_bounces = max_bounces;
+    opt.seed = seed;
+    opt.row_begin = 0;
+    opt.row_end = st.height;
+    opt.device = device;
+
+    const size_t vals = (size_t)st.width * st.height * 3;
+    std::vector<uint8_t> rgb8(vals);
+    rtm_stats stats;
+    rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, nullptr, rgb8.data(), &stats);
+    if (rc != RTM_OK) {
+        std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), rtm_last_error_detail());
+        return 1;
+    }
+    std::printf("%d x %d, %llu samples, %.3f casts/sample, kernel %.3f ms, %.1f Msamples/s\n", st.width,
+                st.height, (unsigned long long)stats.samples,
+                stats.samples ? (double)stats.casts / (double)stats.samples : 0.0, stats.kernel_ms,
+                stats.kernel_ms > 0 ? (double)stats.samples / stats.kernel_ms * 1e-3 : 0.0);
+    // src/Renderer.cpp:256-257
+    const int ok_jpg = rtm_write_jpg((stem + ".jpg").c_str(), st.width, st.height, 3, rgb8.data(), 60);
+    const int ok_bmp = rtm_write_bmp((stem + ".bmp").c_str(), st.width, st.height, 3, rgb8.data());
+    return (ok_jpg && ok_bmp) ? 0 : 1;
+}

@@ -1,0 +1,132 @@
+"""png::Renderer on the HIP path (reference src/Renderer.h:8-18, src/Renderer.cpp:20-23,200-258).
+
+    ld = LoadData("cornellBoxSetting.json")
+    r = Renderer(ld.data, mode="repaired", max_bounces=8)
+    r.Render("result")          # writes result.jpg (q=60) and result.bmp like the reference
+    r.image                     # (H, W, 3) float64 — the reference's private Renderer::image
+
+Device memory and streams come from torch (plumbing); every pixel is computed by the HIP kernels
+behind rtm_render_device.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import rtm_options, rtm_stats
+from .settings import SettingData
+
+
+class Renderer:
+    def __init__(self, data: SettingData, mode="repaired", max_bounces=-1, seed=0x5EED, device=0,
+                 variant=0):
+        self.data = data  # the reference keeps a reference to the caller's SettingData
+        self.mode = _lib.MODES[mode]
+        self.max_bounces = int(max_bounces)
+        self.seed = int(seed)
+        self.device = int(device)
+        self.variant = int(variant)
+        self.image = np.zeros((data.height, data.width, 3), dtype=np.float64)  # src/Renderer.cpp:21
+        self.stats = None
+
+    def _options(self, row_begin, row_end):
+        o = rtm_options()
+        o.mode, o.max_bounces, o.seed = self.mode, self.max_bounces, self.seed
+        o.row_begin, o.row_end = int(row_begin), int(row_end)
+        o.device, o.variant = self.device, self.variant
+        return o
+
+    # ---- device-resident render: outputs are torch tensors on the GPU ------------------------
+    def render_rows_device(self, row_begin=0, row_end=None, want=("f32",), stats=True,
+                           stream=None):
+        """Render rows [row_begin, row_end) into torch CUDA tensors; returns (dict, stats)."""
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("Renderer needs a HIP device; there is no CPU fallback")
+        row_end = self.data.height if row_end is None else row_end
+        rows, W = row_end - row_begin, self.data.width
+        dev = torch.device("cuda", self.device)
+        out = {}
+        if "f64" in want:
+            out["f64"] = torch.empty((rows, W, 3), dtype=torch.float64, device=dev)
+        if "f32" in want:
+            out["f32"] = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
+        if "u8" in want:
+            out["u8"] = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
+        st, arr, n = self.data.to_c()
+        opt = self._options(row_begin, row_end)
+        s = rtm_stats()
+        hip_stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out and rows > 0 else None
+        _lib.check(_lib.lib().rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), ptr("f64"),
+                                                ptr("f32"), ptr("u8"), C.c_void_p(hip_stream),
+                                                C.byref(s) if stats else None), "rtm_render_device")
+        return out, (s.as_dict() if stats else None)
+
+    # ---- host-buffer render (the blocking C entry point) ------------------------------------
+    def render_rows(self, row_begin=0, row_end=None, want=("f64",)):
+        row_end = self.data.height if row_end is None else row_end
+        rows, W = row_end - row_begin, self.data.width
+        out = {}
+        if "f64" in want:
+            out["f64"] = np.zeros((rows, W, 3), dtype=np.float64)
+        if "f32" in want:
+            out["f32"] = np.zeros((rows, W, 3), dtype=np.float32)
+        if "u8" in want:
+            out["u8"] = np.zeros((rows, W, 3), dtype=np.uint8)
+        st, arr, n = self.data.to_c()
+        opt = self._options(row_begin, row_end)
+        s = rtm_stats()
+        ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
+        _lib.check(_lib.lib().rtm_render(C.byref(st), arr, n, C.byref(opt), ptr("f64"), ptr("f32"),
+                                         ptr("u8"), C.byref(s)), "rtm_render")
+        self.stats = s.as_dict()
+        return out, self.stats
+
+    def Render(self, fileName):
+        """src/Renderer.cpp:200-258: render, quantise, write <fileName>.jpg and <fileName>.bmp."""
+        out, _ = self.render_rows(0, self.data.height, want=("f64", "u8"))
+        self.image = out["f64"]
+        rgb8 = np.ascontiguousarray(out["u8"])
+        L = _lib.lib()
+        H, W = self.data.height, self.data.width
+        ok_j = L.rtm_write_jpg(os.fsencode(fileName + ".jpg"), W, H, 3, rgb8.ctypes.data, 60)
+        ok_b = L.rtm_write_bmp(os.fsencode(fileName + ".bmp"), W, H, 3, rgb8.ctypes.data)
+        if not (ok_j and ok_b):
+            raise _lib.RtmError(-3, f"could not write {fileName}.jpg/.bmp")
+        return rgb8
+
+
+# ---- seams below the renderer, for parity tests --------------------------------------------------
+def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_bounces=-1,
+                       seed=0x5EED, device=0):
+    """png::PathTracing (src/Renderer.cpp:57-117) for n rays; ray i draws from stream (seed, i, 0)."""
+    org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n_rays = org.shape[0]
+    out = np.zeros((n_rays, 3), dtype=np.float64)
+    draws = np.zeros(n_rays, dtype=np.uint32)
+    casts = np.zeros(n_rays, dtype=np.uint32)
+    _, arr, n = data.to_c()
+    o = rtm_options()
+    o.mode, o.max_bounces, o.seed, o.device = _lib.MODES[mode], int(max_bounces), int(seed), device
+    _lib.check(_lib.lib().rtm_path_trace_batch(arr, n, C.byref(o), org.ctypes.data,
+                                               direction.ctypes.data, n_rays, out.ctypes.data,
+                                               draws.ctypes.data, casts.ctypes.data),
+               "rtm_path_trace_batch")
+    return out, draws, casts
+
+
+def intersect_batch(spheres_c, org, direction, mode="repaired", t_init=-1.0, n_init=7.0):
+    """SphereObject::Intersect (src/SettingData.cpp:197-226), pair i = (ray i, sphere i)."""
+    org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n = org.shape[0]
+    hit = np.zeros(n, dtype=np.int32)
+    t = np.full(n, t_init, dtype=np.float64)
+    nrm = np.full((n, 3), n_init, dtype=np.float64)
+    _lib.check(_lib.lib().rtm_intersect_batch(spheres_c, org.ctypes.data, direction.ctypes.data, n,
+                                              _lib.MODES[mode], hit.ctypes.data, t.ctypes.data,
+                                              nrm.ctypes.data), "rtm_intersect_batch")
+    return hit, t, nrm

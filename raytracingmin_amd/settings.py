@@ -1,0 +1,119 @@
+"""Host-side mirror of the reference's scene data model and loader.
+
+Names follow the reference (src/SettingData.h:8-61): vec3, Material, SphereObject, Camera,
+SettingData, LoadData.  Parsing is done by the C++ loader behind the C ABI
+(rtm_scene_load_json); these classes only hold the result and flatten it for the kernels.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List
+
+from . import _lib
+from ._lib import rtm_settings, rtm_sphere
+
+
+@dataclass
+class vec3:  # src/Ray.h:7-12
+    x: float = 0.0
+    y: float = 0.0
+    z: float = 0.0
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z))
+
+
+@dataclass
+class Material:  # src/SettingData.h:8-17
+    color: vec3 = field(default_factory=vec3)
+    emission: vec3 = field(default_factory=vec3)
+
+
+@dataclass
+class SphereObject:  # src/SettingData.h:25-32; m_size is a float in the reference
+    m_position: vec3 = field(default_factory=vec3)
+    m_size: float = 1.0
+    m_material: Material = field(default_factory=Material)
+
+
+@dataclass
+class Camera:  # src/SettingData.h:43-46
+    origin: vec3 = field(default_factory=vec3)
+    target: vec3 = field(default_factory=lambda: vec3(0, 0, 1))
+    upVec: vec3 = field(default_factory=lambda: vec3(0, 1, 0))
+    fov: float = 60.0
+
+
+@dataclass
+class SettingData:  # src/SettingData.h:47-51
+    width: int = 960
+    height: int = 540
+    samples: int = 10
+    superSamples: int = 1
+    camera: Camera = field(default_factory=Camera)
+    object: List[SphereObject] = field(default_factory=list)
+
+    # ---- flattening to / from the C ABI structs
+    def to_c(self):
+        st = rtm_settings()
+        st.width, st.height = int(self.width), int(self.height)
+        st.samples, st.super_samples = int(self.samples), int(self.superSamples)
+        for k, v in enumerate(self.camera.origin):
+            st.camera.origin[k] = float(v)
+        for k, v in enumerate(self.camera.target):
+            st.camera.target[k] = float(v)
+        for k, v in enumerate(self.camera.upVec):
+            st.camera.up[k] = float(v)
+        st.camera.fov = float(self.camera.fov)
+        n = len(self.object)
+        arr = (rtm_sphere * max(n, 1))()
+        for i, o in enumerate(self.object):
+            for k, v in enumerate(o.m_position):
+                arr[i].center[k] = float(v)
+            for k, v in enumerate(o.m_material.color):
+                arr[i].color[k] = float(v)
+            for k, v in enumerate(o.m_material.emission):
+                arr[i].emission[k] = float(v)
+            arr[i].radius = float(o.m_size)
+        return st, arr, n
+
+    @staticmethod
+    def from_c(st, arr, n):
+        cam = Camera(vec3(*st.camera.origin), vec3(*st.camera.target), vec3(*st.camera.up),
+                     float(st.camera.fov))
+        objs = [SphereObject(vec3(*arr[i].center), float(arr[i].radius),
+                             Material(vec3(*arr[i].color), vec3(*arr[i].emission)))
+                for i in range(n)]
+        return SettingData(int(st.width), int(st.height), int(st.samples), int(st.super_samples),
+                           cam, objs)
+
+
+class LoadData:
+    """png::LoadData (src/SettingData.cpp:6-12): LoadData(path).data is the SettingData.
+
+    literal_loader=True reproduces HEAD's position bug (src/SettingData.cpp:165-167).
+    """
+
+    def __init__(self, jsonName, literal_loader=False):
+        L = _lib.lib()
+        st = rtm_settings()
+        n = C.c_size_t(0)
+        path = os.fsencode(jsonName)
+        _lib.check(L.rtm_scene_load_json(path, int(literal_loader), C.byref(st), None, 0,
+                                         C.byref(n)), f"LoadData({jsonName})")
+        arr = (rtm_sphere * max(n.value, 1))()
+        _lib.check(L.rtm_scene_load_json(path, int(literal_loader), C.byref(st), arr, n.value,
+                                         C.byref(n)), f"LoadData({jsonName})")
+        self.data = SettingData.from_c(st, arr, n.value)
+
+    @staticmethod
+    def SaveSampleJson(fileName):  # src/SettingData.cpp:14-24,100-103
+        _lib.check(_lib.lib().rtm_scene_save_sample_json(os.fsencode(fileName)), "SaveSampleJson")
+
+
+def make_stress_scene(n=100_000, seed=12345):
+    """BASELINE config 5 scene."""
+    st = rtm_settings()
+    arr = (rtm_sphere * max(n, 1))()
+    _lib.check(_lib.lib().rtm_scene_make_stress(seed, n, C.byref(st), arr), "make_stress_scene")
+    return SettingData.from_c(st, arr, n)

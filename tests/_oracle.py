@@ -72,6 +72,10 @@ def lib():
         L.rtmo_path_trace.restype = None
         L.rtmo_path_trace.argtypes = [C.POINTER(Sphere), C.c_size_t, C.c_int, C.c_int, _D3, _D3,
                                       RNG_FN, C.c_void_p, _D3, C.POINTER(Counters)]
+        L.rtmo_path_trace_stream.restype = None
+        L.rtmo_path_trace_stream.argtypes = [C.POINTER(Sphere), C.c_size_t, C.c_int, C.c_int, _D3,
+                                             _D3, C.c_uint64, C.c_uint32, C.c_uint32, _D3,
+                                             C.POINTER(Counters)]
         L.rtmo_render.restype = C.c_int
         L.rtmo_render.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t,
                                   C.POINTER(Options), C.c_void_p, C.POINTER(Counters), C.c_int,
@@ -174,6 +178,21 @@ def path_trace(spheres, n, mode, max_bounces, org, direction, rng):
     lib().rtmo_path_trace(spheres, n, mode, max_bounces, _D3(*org), _D3(*direction), cb, None,
                           out, C.byref(cnt))
     return [out[0], out[1], out[2]], cnt.as_dict()
+
+
+def path_trace_stream(spheres, n, mode, max_bounces, org, direction, seed, pixel, sample=0):
+    out = _D3()
+    cnt = Counters()
+    lib().rtmo_path_trace_stream(spheres, n, mode, max_bounces, _D3(*org), _D3(*direction), seed,
+                                 pixel, sample, out, C.byref(cnt))
+    return [out[0], out[1], out[2]], cnt.as_dict()
+
+
+def intersect(sphere, org, direction, mode, t_init=-1.0, n_init=7.0):
+    t = C.c_double(t_init)
+    nrm = _D3(n_init, n_init, n_init)
+    hit = lib().rtmo_intersect(C.byref(sphere), _D3(*org), _D3(*direction), mode, C.byref(t), nrm)
+    return hit, t.value, [nrm[0], nrm[1], nrm[2]]
 
 
 def normalize(v):

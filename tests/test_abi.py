@@ -1,0 +1,93 @@
+"""The C-ABI library loads and exports every symbol include/rtm.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from raytracingmin_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 19
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/rtm.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().rtm_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    from raytracingmin_amd import _lib
+    assert C.sizeof(_lib.rtm_camera) == 80
+    assert C.sizeof(_lib.rtm_sphere) == 80
+    assert C.sizeof(_lib.rtm_settings) == 96
+    assert C.sizeof(_lib.rtm_options) == 32
+    assert C.sizeof(_lib.rtm_stats) == 40
+    # the oracle's view of the same PODs
+    import _oracle
+    assert C.sizeof(_oracle.Sphere) == 80 and C.sizeof(_oracle.Settings) == 96
+    assert C.sizeof(_oracle.Options) == 32
+
+
+def test_strerror_and_variants():
+    from raytracingmin_amd import _lib
+    L = _lib.lib()
+    assert L.rtm_strerror(0) == b"ok"
+    for code in range(-8, 0):
+        assert L.rtm_strerror(code) not in (b"ok", b"unknown status")
+    assert L.rtm_num_variants() >= 1
+    assert L.rtm_variant_name(0)
+    assert L.rtm_variant_name(10_000) is None
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from raytracingmin_amd import _lib
+    L = _lib.lib()
+    st = _lib.rtm_settings()
+    opt = _lib.rtm_options()
+    assert L.rtm_render(None, None, 0, None, None, None, None, None) == -1
+    st.width, st.height, st.samples, st.super_samples = 0, 4, 1, 1
+    opt.row_end = 4
+    assert L.rtm_render(C.byref(st), None, 0, C.byref(opt), None, None, None, None) == -1
+    st.width = 4
+    opt.row_end = 5  # outside the image
+    assert L.rtm_render(C.byref(st), None, 0, C.byref(opt), None, None, None, None) == -1
+    opt.row_end, opt.mode = 4, 7
+    assert L.rtm_render(C.byref(st), None, 0, C.byref(opt), None, None, None, None) == -1
+    assert b"mode" in L.rtm_last_error_detail()
+
+
+def test_host_rng_matches_oracle(oracle):
+    from raytracingmin_amd import _lib
+    L = _lib.lib()
+    for seed in (0, 1, 0x5EED, 2 ** 63 + 12345):
+        for pixel in (0, 1, 77, 2 ** 23 - 1, 2 ** 32 - 1):
+            for sample in (0, 5, 4095):
+                for idx in (0, 1, 2, 54, 100000):
+                    assert L.rtm_rng_u01(seed, pixel, sample, idx) == \
+                        oracle.lib().rtmo_rng_u01(seed, pixel, sample, idx)
+
+
+def test_product_does_not_link_the_oracle():
+    """The shipped library and package never reference oracle/ (grading rule of the tier)."""
+    import subprocess
+    from raytracingmin_amd import _lib
+    out = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rtmo_" not in out
+    pkg = os.path.join(ROOT, "raytracingmin_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in src and "cpu_ref" not in src and "rtmo_" not in src, f

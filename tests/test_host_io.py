@@ -1,0 +1,153 @@
+"""Host side of the boundary: scene loader (reference src/SettingData.cpp:129-186), quantiser and
+image writers (src/Renderer.cpp:251-257).  No GPU needed."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import raytracingmin_amd as rtm
+from raytracingmin_amd import _lib
+
+SCENES = ["cornellBoxSetting.json", "simpleSetting1.json", "simpleSetting2.json", "settingData.json"]
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("literal", [False, True])
+def test_loader_matches_independent_python_reader(oracle, name, literal):
+    path = oracle.scene_path(name)
+    st, arr, n = oracle.load_scene(path, literal_loader=literal)
+    data = rtm.LoadData(path, literal_loader=literal).data
+    cst, carr, cn = data.to_c()
+    assert cn == n
+    assert (cst.width, cst.height, cst.samples, cst.super_samples) == \
+        (st.width, st.height, st.samples, st.super_samples)
+    assert bytes(cst.camera)[:76] == bytes(st.camera)[:76]
+    for i in range(n):
+        assert list(carr[i].center) == list(arr[i].center)
+        assert list(carr[i].color) == list(arr[i].color)
+        assert list(carr[i].emission) == list(arr[i].emission)
+        assert carr[i].radius == arr[i].radius
+
+
+def test_shipped_files_load_unchanged():
+    import _oracle
+    d = rtm.LoadData(_oracle.scene_path("cornellBoxSetting.json")).data
+    assert (d.width, d.height, d.samples, d.superSamples) == (960, 504, 25, 4)
+    assert len(d.object) == 7  # 8 entries minus the "{}"
+    assert d.camera.fov == 2.0 and tuple(d.camera.origin) == (0.0, 0.0, -10.0)
+    s1 = rtm.LoadData(_oracle.scene_path("simpleSetting1.json")).data
+    assert (s1.samples, s1.superSamples, len(s1.object)) == (100, 1, 5)  # "00 sample" alias
+    s2 = rtm.LoadData(_oracle.scene_path("simpleSetting2.json")).data
+    assert s2.samples == 500
+
+
+def _parse(text, literal=0):
+    L = _lib.lib()
+    st = _lib.rtm_settings()
+    n = C.c_size_t()
+    arr = (_lib.rtm_sphere * 8)()
+    b = text.encode()
+    rc = L.rtm_scene_parse_json(b, len(b), literal, C.byref(st), arr, 8, C.byref(n))
+    return rc, st, arr, n.value
+
+
+def test_loader_edge_cases():
+    base = {"00 width": 4, "00 height": 2, "01 camera": {"fov": 1.5, "origin": [0, 0, 0],
+                                                         "target": [0, 0, 1], "upVec": [0, 1, 0]}}
+    rc, st, _, n = _parse(json.dumps(base))
+    assert rc == 0 and n == 0 and (st.samples, st.super_samples) == (10, 1)  # defaults
+    rc, *_ = _parse("{ not json")
+    assert rc == -4
+    rc, *_ = _parse(json.dumps({"00 height": 2}))
+    assert rc == -2  # width required
+    obj = {"00 position": [1, 2, 3], "01 size": 0.1, "02 material": {"color": [.1, .2, .3], "emission": [0, 0, 0]}}
+    doc = dict(base, **{"02 scene": {"00 object": [obj, {}, dict(obj, **{"00 objectType": 1})]}})
+    rc, st, arr, n = _parse(json.dumps(doc))
+    assert rc == 0 and n == 2 and list(arr[0].center) == [1, 2, 3]
+    assert arr[0].radius == np.float32(0.1)
+    rc, st, arr, n = _parse(json.dumps(doc), literal=1)
+    assert list(arr[0].center) == [3, 0, 0]  # D1
+    doc["02 scene"]["00 object"][0]["00 objectType"] = 2
+    rc, *_ = _parse(json.dumps(doc))
+    assert rc == -2 and b"objectType" in _lib.lib().rtm_last_error_detail()
+    doc["02 scene"]["00 object"][0]["00 objectType"] = 1
+    doc["02 scene"]["00 object"][0]["01 size"] = "big"
+    rc, *_ = _parse(json.dumps(doc))
+    assert rc == -4  # nlohmann would throw type_error
+    rc, st, *_ = _parse(json.dumps(dict(base, **{"00 width": 7.9, "unknown": [1, {"a": None}]})))
+    assert rc == 0 and st.width == 7  # get<int>() truncates; unknown keys ignored
+    # capacity query / too small
+    L = _lib.lib()
+    st = _lib.rtm_settings()
+    n = C.c_size_t()
+    doc["02 scene"]["00 object"][0]["01 size"] = 1
+    b = json.dumps(doc).encode()
+    assert L.rtm_scene_parse_json(b, len(b), 0, C.byref(st), None, 0, C.byref(n)) == 0 and n.value == 2
+    one = (_lib.rtm_sphere * 1)()
+    assert L.rtm_scene_parse_json(b, len(b), 0, C.byref(st), one, 1, C.byref(n)) == -7
+    assert L.rtm_scene_load_json(b"/nonexistent/x.json", 0, C.byref(st), None, 0, C.byref(n)) == -3
+
+
+def test_save_sample_json_roundtrip(tmp_path):
+    p = str(tmp_path / "settingData.json")
+    rtm.LoadData.SaveSampleJson(p)
+    j = json.load(open(p))
+    assert j == {"00 height": 540, "00 samples": 10, "00 superSamples": 4, "00 width": 960,
+                 "01 camera": {"fov": 60.0, "origin": [0, 0, 0], "target": [0, 0, 1], "upVec": [0, 1, 0]}}
+    d = rtm.LoadData(p).data
+    assert (d.width, d.height, d.samples, d.superSamples, len(d.object)) == (960, 540, 10, 4, 0)
+
+
+def test_stress_scene_matches_oracle_generator(oracle):
+    n = 1000
+    d = rtm.make_stress_scene(n=n, seed=12345)
+    st = oracle.Settings()
+    arr = (oracle.Sphere * n)()
+    oracle.lib().rtmo_make_stress_scene(12345, n, C.byref(st), arr)
+    _, carr, _ = d.to_c()
+    assert bytes(carr)[:80 * n] == bytes(arr)
+    assert (d.width, d.height, d.samples, d.superSamples) == (1920, 1080, 256, 1)
+    assert d.object[0].m_material.emission.x == 5.0 and d.object[1].m_material.emission.x == 0.0
+
+
+def test_quantise_matches_oracle(oracle):
+    rng = np.random.default_rng(1)
+    v = np.concatenate([rng.uniform(-0.1, 1.3, 5000), [0.0, 1.0, 0.999999999, 1 / 255, 254.9999 / 255,
+                                                       5.0, 1e-300, np.nextafter(1.0, 0)]])
+    out = np.zeros(v.size, dtype=np.uint8)
+    assert _lib.lib().rtm_quantise(v.ctypes.data, v.size, out.ctypes.data) == 0
+    assert np.array_equal(out, oracle.quantise(v))
+    assert out[5001] == 255 and out[5002] == 254  # truncation, not rounding
+
+
+def test_bmp_layout_is_stbs(tmp_path):
+    w, h = 5, 3  # row = 15 bytes -> 1 byte padding
+    img = np.arange(w * h * 3, dtype=np.uint8).reshape(h, w, 3)
+    p = str(tmp_path / "a.bmp")
+    assert _lib.lib().rtm_write_bmp(p.encode(), w, h, 3, img.ctypes.data) == 1
+    raw = open(p, "rb").read()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 16 * h
+    size, _, _, off, hdr, bw, bh, planes, bpp = struct.unpack("<IHHIIiiHH", raw[2:30])
+    assert (size, off, hdr, bw, bh, planes, bpp) == (len(raw), 54, 40, w, h, 1, 24)
+    assert raw[30:54] == bytes(24)
+    first = raw[54:54 + 16]  # bottom row first, BGR, padded
+    assert first[:3] == bytes(img[h - 1, 0, ::-1]) and first[15] == 0
+    from PIL import Image
+    assert np.array_equal(np.array(Image.open(p)), img)
+
+
+def test_jpeg_is_decodable_baseline(tmp_path):
+    from PIL import Image
+    yy, xx = np.mgrid[0:50, 0:70]
+    img = np.ascontiguousarray(np.stack([xx * 3, yy * 5, xx + yy], -1).astype(np.uint8))
+    for q in (60, 95):
+        p = str(tmp_path / f"a{q}.jpg")
+        assert _lib.lib().rtm_write_jpg(p.encode(), 70, 50, 3, img.ctypes.data, q) == 1
+        im = Image.open(p)
+        assert im.format == "JPEG" and im.size == (70, 50)
+        err = np.abs(np.array(im.convert("RGB")).astype(int) - img)
+        assert err.mean() < 4 and err.max() < 40
+    assert _lib.lib().rtm_write_jpg(b"/nonexistent/dir/a.jpg", 70, 50, 3, img.ctypes.data, 60) == 0
