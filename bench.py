@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over the headline workload (BASELINE.json configs[2]):
+Cornell box (tests/golden/scenes/cornellBoxSetting.json, unchanged), 1920x1080, 1024 spp
+(superSamples 4 x samples 64), repaired (L1) semantics, max 8 bounces, fp64, seed 0x5EED, rendered
+into the HBM-resident float3 accumulation buffer.  With N > 1 the image is split into N contiguous
+row strips, one per rank (total work fixed => "strong"), and one RCCL gather to rank 0 ends every
+step inside the timed region.  metric = Msamples/s = W*H*spp / s, whole job.
+
+Extra objects on the JSON line:
+  roofline     — the binding roof of the render kernel is the fp64 vector ALU, so
+                 achieved = algorithmic flops per launch / average kernel time (HIP events on the
+                 launch stream); an "hbm" sub-object carries the achieved HBM GB/s the metric asks
+                 for (algorithmic bytes: the float3 image written once + the scene read).
+  cpu_baseline — the CPU oracle (oracle/cpu_ref.c, OpenMP, all host cores) on a bounded sample of
+                 the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HEADLINE = dict(scene="cornellBoxSetting.json", width=1920, height=1080, samples=64, super_samples=4,
+                mode="repaired", max_bounces=8, seed=0x5EED)
+PEAK_FP64_VECTOR_TFLOPS = 78.6   # AMD datasheet (FMA = 2 flops); MI355X_MICROARCH.md has fp32 157.3
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md chip table (spec)
+
+
+def algorithmic_flops_per_sample(n_spheres, casts_per_sample, bounces_per_sample, d4_fraction):
+    """F_sample = 50 + C*F_cast + B*F_bounce; F_cast = 17 N + 3 N_{D4>=0} + 18;
+    F_bounce = 83.  C, B measured by the kernel's counters, N_{D4>=0} by the oracle's."""
+    f_cast = 17.0 * n_spheres + 3.0 * n_spheres * d4_fraction + 18.0
+    return 50.0 + casts_per_sample * f_cast + bounces_per_sample * 83.0
+
+
+def cpu_baseline(cfg, budget_rows):
+    """Time the CPU oracle on `budget_rows` full-width rows of the headline workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle
+    st, arr, n = _oracle.load_scene(_oracle.scene_path(cfg["scene"]), width=cfg["width"],
+                                    height=cfg["height"], samples=cfg["samples"],
+                                    super_samples=cfg["super_samples"])
+    threads = _oracle.lib().rtmo_max_threads()
+    r0 = cfg["height"] // 2 - budget_rows // 2
+    opt = _oracle.make_options(mode=1, max_bounces=cfg["max_bounces"], seed=cfg["seed"],
+                               row_begin=r0, row_end=r0 + budget_rows)
+    # warm the thread pool on one row
+    _oracle.render(st, arr, n, _oracle.make_options(mode=1, max_bounces=cfg["max_bounces"],
+                                                    seed=cfg["seed"], row_begin=0, row_end=1))
+    t0 = time.perf_counter()
+    _, cnt = _oracle.render(st, arr, n, opt, threads=threads, structure=0)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    _oracle.render(st, arr, n, _oracle.make_options(mode=1, max_bounces=cfg["max_bounces"],
+                                                    seed=cfg["seed"], row_begin=r0,
+                                                    row_end=r0 + max(1, budget_rows // 8)),
+                   threads=threads, structure=1, want_counters=False)
+    dt_ref = time.perf_counter() - t1
+    samples_ref = max(1, budget_rows // 8) * cfg["width"] * cfg["samples"] * cfg["super_samples"] ** 2
+    return {
+        "value": cnt["samples"] / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"rows {r0}..{r0 + budget_rows} of the headline frame at full 1024 spp "
+                  f"({cnt['samples']} samples, {dt:.2f} s wall, OpenMP per-pixel parallel)",
+        "reference_loop_structure_value": samples_ref / dt_ref / 1e6,
+        "casts_per_sample": cnt["casts"] / cnt["samples"],
+        "d4_fraction": cnt["sphere_tests_d4"] / max(1, cnt["sphere_tests"]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=HEADLINE["width"])
+    ap.add_argument("--height", type=int, default=HEADLINE["height"])
+    ap.add_argument("--samples", type=int, default=HEADLINE["samples"])
+    ap.add_argument("--super-samples", type=int, default=HEADLINE["super_samples"])
+    ap.add_argument("--max-bounces", type=int, default=HEADLINE["max_bounces"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracingmin_amd as rtm
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
+               super_samples=args.super_samples, max_bounces=args.max_bounces)
+    scene = os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"])
+    data = rtm.LoadData(scene).data
+    data.width, data.height = cfg["width"], cfg["height"]
+    data.samples, data.superSamples = cfg["samples"], cfg["super_samples"]
+    spp = cfg["samples"] * cfg["super_samples"] ** 2
+
+    from raytracingmin_amd.distributed import StripRenderer
+    sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
+                       max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sr.step()
+    # kernel time and counters of one instrumented launch (outside the timed region)
+    barrier()
+    stats = sr.step(stats=True)
+    barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        sr.step(events=ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    total_samples = cfg["width"] * cfg["height"] * spp
+    value = total_samples * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        n_spheres = len(data.object)
+        cps = stats["casts"] / stats["samples"]
+        bps = stats["bounces"] / stats["samples"]
+        cpu = None
+        d4 = 0.93
+        if world == 1 and args.cpu_rows > 0:
+            cpu = cpu_baseline(cfg, args.cpu_rows)
+            d4 = cpu["d4_fraction"]
+        f_sample = algorithmic_flops_per_sample(n_spheres, cps, bps, d4)
+        rank_samples = stats["samples"]  # samples one launch of this rank processed
+        flops_per_launch = f_sample * rank_samples
+        achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        rows0 = sr.rows[1] - sr.rows[0]
+        alg_bytes = rows0 * cfg["width"] * 12 + n_spheres * 96
+        hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp", "value": value,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ExampleScene/cornellBoxSetting.json {cfg['width']}x{cfg['height']} "
+                                   f"{spp}spp (SS {cfg['super_samples']} x S {cfg['samples']}), L1 repaired, "
+                                   f"max_bounces {cfg['max_bounces']}, seed 0x5EED, row strips over "
+                                   f"{world} GPU(s) + one gather",
+                       "variant": rtm.lib().rtm_variant_name(args.variant).decode(),
+                       "casts_per_sample": cps, "bounces_per_sample": bps},
+            "roofline": {
+                "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": None,
+                "kernel": "render_tiles_kernel", "kernel_ms": kernel_ms,
+                "flops_per_sample": f_sample,
+                "note": "no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM "
+                        "traffic; peak counts FMA as 2 flops but parity forbids contraction, so the "
+                        "attainable ceiling is <= 0.5",
+                "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
+            },
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,18 @@ _EXTRA = {"rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 (same SONAME as
+    /opt/rocm's); two copies in one process leave the second without a device.  Importing torch
+    BEFORE librtm_hip.so is loaded makes the dynamic loader resolve our libamdhip64.so.7
+    dependency to the copy torch already mapped, so tensors, streams and RCCL buffers torch owns
+    are valid in our kernels.  Without torch (rtm_cli, plain C callers) /opt/rocm's is used."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """The loaded HIP library; raises (never falls back) when it is missing."""
     global _lib
@@ -96,6 +108,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` or `make -C raytracingmin_amd/csrc`. There is no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

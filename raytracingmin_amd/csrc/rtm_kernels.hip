@@ -385,6 +385,7 @@ const char* last_error() { return g_last_error.c_str(); }
     do {                                                                                  \
         hipError_t e__ = (expr);                                                          \
         if (e__ != hipSuccess) {                                                          \
+            (void)hipGetLastError(); /* do not leave a sticky error for the host app */  \
             set_last_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
             return RTM_ERR_HIP;                                                           \
         }                                                                                 \
