@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--super-samples", type=int, default=HEADLINE["super_samples"])
     ap.add_argument("--max-bounces", type=int, default=HEADLINE["max_bounces"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -118,6 +119,25 @@ def main():
     from raytracingmin_amd.distributed import StripRenderer
     sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
                        max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant)
+
+    if args.ab:
+        # interleaved rounds in ONE process (guide rule 24): median/min kernel ms per variant
+        from raytracingmin_amd.renderer import Renderer
+        vs = [int(v) for v in args.ab.split(",")]
+        rs = {v: Renderer(data, mode=cfg["mode"], max_bounces=cfg["max_bounces"], seed=cfg["seed"],
+                          device=local_rank, variant=v) for v in vs}
+        times = {v: [] for v in vs}
+        for rnd in range(args.steps + args.warmup):
+            for v in vs:
+                _, st = rs[v].render_rows_device(want=("f32",), stats=True)
+                if rnd >= args.warmup:
+                    times[v].append(st["kernel_ms"])
+        for v in vs:
+            t = sorted(times[v])
+            print(json.dumps({"variant": v, "name": rtm.lib().rtm_variant_name(v).decode(),
+                              "kernel_ms_median": t[len(t) // 2], "kernel_ms_min": t[0],
+                              "Msamples_per_s_median": cfg["width"] * cfg["height"] * spp / t[len(t) // 2] / 1e3}), flush=True)
+        return
 
     def barrier():
         if world > 1:

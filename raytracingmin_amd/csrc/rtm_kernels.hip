@@ -26,22 +26,15 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rtm.h"
 #include "rtm_device.h"
 #include "rtm_internal.h"
+#include "rtm_path.h"
 
 namespace rtm {
-
-// ------------------------------------------------------------------------------------------------
-// Scene as the kernels see it.  geom[i] = (cx, cy, cz, (double)(float)(r*r)): 32 B per sphere.
-// mat[i*8 + 0..7] = colorKD.xyz, kd (float widened), emission.xyz, pad: 64 B per sphere.
-struct SceneView {
-    const double4* __restrict__ geom;
-    const double* __restrict__ mat;
-    int n;
-};
 
 struct RenderParams {
     SceneView scene;
@@ -52,6 +45,7 @@ struct RenderParams {
     unsigned total_samples;  // SS*SS*S per pixel
     float rate;              // 1.0 / (1 + SS) as float, src/Renderer.cpp:227
     double dSS, dS;          // divisors of src/Renderer.cpp:240
+    double inv_ss, inv_s;    // exact reciprocals when SS and S are powers of two, else 0
     D3 cam_org, ax, by, cz;  // origin, camX*fovx, camY*fovy, camZ (src/Renderer.cpp:202-208)
     uint64_t seed_mult;
     double* __restrict__ out64;
@@ -59,115 +53,6 @@ struct RenderParams {
     uint8_t* __restrict__ out8;
     unsigned long long* __restrict__ counters;  // casts, bounces, draws, overflow flag
 };
-
-// src/SettingData.cpp:197-226 without the normal: returns hit and t.
-__device__ __forceinline__ bool sphere_test(const double4 g, const D3 org, const D3 dir,
-                                            double& t) {
-    const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // :198
-    const double b = dot(p_o, dir);                            // :199
-    const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200 (g.w = float r*r widened)
-    if (D4 < 0.0) return false;                                // :202
-    const double sq = sqrt(D4);                                // :205
-    const double t1 = b - sq, t2 = b + sq;
-    const double min_value = (double)1e-5f;                    // :208
-    if (t1 < min_value && t2 < min_value) return false;        // :209
-    t = (t1 > 0.001) ? t1 : t2;                                // :212-223
-    return true;
-}
-// src/SettingData.cpp:214-215: out_normal = Normalize(hitPoint - m_position)
-__device__ __forceinline__ D3 sphere_normal(const double4 g, const D3 hit_point) {
-    return normalize(hit_point - d3(g.x, g.y, g.z));
-}
-
-// src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
-__device__ __forceinline__ int nearest_hit(const SceneView& sc, const D3 org, const D3 dir,
-                                           double& dis) {
-    int hit_object = -1;
-    dis = DBL_MAX;
-    for (int i = 0; i < sc.n; ++i) {
-        const double4 g = sc.geom[i];  // wave-uniform address
-        double t;
-        if (sphere_test(g, org, dir, t) && t < dis && t > 0) {
-            dis = t;
-            hit_object = i;
-        }
-    }
-    return hit_object;
-}
-
-struct PathCounters {
-    unsigned casts, bounces, draws;
-};
-
-// One PathTracing invocation (src/Renderer.cpp:57-117) on the flattened path.
-// Returns true when the path continues (org/dir/depth updated, hit id pushed through `push`);
-// false when it ended with `term` = the value the deepest invocation returned.
-template <typename PushFn>
-__device__ __forceinline__ bool path_step(const SceneView& sc, const int mode,
-                                          const int max_bounces, D3& org, D3& dir, int& depth,
-                                          RngStream& rng, D3& term, PathCounters& pc,
-                                          PushFn push) {
-    double dis;
-    const int id = nearest_hit(sc, org, dir, dis);
-    pc.casts++;
-    if (id < 0) {  // :116
-        term = d3(0, 0, 0);
-        return false;
-    }
-    const double* m = sc.mat + (size_t)id * 8;
-    const D3 emission = d3(m[4], m[5], m[6]);
-    if (max_bounces >= 0 && depth >= max_bounces) {  // build extension: no draw
-        term = emission;
-        return false;
-    }
-    pc.draws++;
-    if (!(rng_next(rng) <= m[3])) {  // :78, kd() is a float widened to double
-        term = emission;             // :112
-        return false;
-    }
-    const D3 hit_point = dir * dis + org;  // :79
-    // D2: in literal mode the caller's normal stays (0,0,0)
-    const D3 normal =
-        (mode == RTM_MODE_LITERAL) ? d3(0, 0, 0) : sphere_normal(sc.geom[id], hit_point);
-    const D3 w = dot(normal, dir) < 0.0 ? normal : normal * -1.0;  // :82-83
-    pc.draws += 2;
-    const double r1 = 6.283185307179586 * rng_next(rng);  // :88  (2*PI folded)
-    const double r2 = rng_next(rng);                      // :89
-    const double r2s = sqrt(r2);                          // :90
-    D3 u;
-    if (fabs(w.x) > (double)FLT_MIN)  // :96
-        u = normalize(cross(d3(0, 1, 0), w));
-    else
-        u = normalize(cross(d3(1, 0, 0), w));
-    const D3 v = cross(w, u);  // :102
-    double sn, cs;
-    sincos(r1, &sn, &cs);
-    const D3 nd = normalize((u * cs) * r2s + (v * sn) * r2s + w * sqrt(1.0 - r2));  // :103-107
-    push(depth, id);
-    depth++;
-    pc.bounces++;
-    org = hit_point;
-    dir = nd;
-    return true;
-}
-
-// Fold the recursion back to front: L = colorKD * L_next + emission (src/Renderer.cpp:109).
-template <typename PopFn>
-__device__ __forceinline__ D3 path_fold(const SceneView& sc, const D3 term, const int depth,
-                                        PopFn pop) {
-    D3 L = term;
-    for (int d = depth - 1; d >= 0; --d) {
-        const double* m = sc.mat + (size_t)pop(d) * 8;
-        L = d3(m[0], m[1], m[2]) * L + d3(m[4], m[5], m[6]);
-    }
-    return L;
-}
-
-// src/Renderer.cpp:43-49: std::min<double>(std::max<double>(v, 0), 1.0f)
-__device__ __forceinline__ double clamp01(double v) {
-    const double lo = (v < 0.0) ? 0.0 : v;
-    return (1.0 < lo) ? 1.0 : lo;
-}
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
 __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
@@ -183,19 +68,39 @@ __device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsign
 }
 
 // ------------------------------------------------------------------------------------------------
-// The render kernel.  RecT: hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged
-// in LDS per lane.
-template <typename RecT, int LDS_D>
+// The render kernel.
+//   M       Math policy (rtm_path.h)
+//   LDS_TAB scene tables (centres + materials) copied to LDS for the per-lane look-ups
+//   UNROLL  spheres whose geometry is fetched together (wave-uniform loads)
+//   RecT    hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged in LDS per lane
+// Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat n*8 doubles][records].
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D>
 __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) {
-    __shared__ RecT rec[LDS_D * 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
+    double* lgeom = reinterpret_cast<double*>(lds_raw);
+    double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
+    RecT* rec = reinterpret_cast<RecT*>(lmat + (LDS_TAB ? P.scene.n * 8 : 0));
+    if constexpr (LDS_TAB) {
+        const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
+        for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
+        for (int i = lane; i < P.scene.n * 8; i += 64) lmat[i] = P.scene.mat[i];
+        __syncthreads();  // one wave per block: orders the LDS writes before the reads
+    }
+    using Scene = typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type;
+    Scene sc;
+    sc.v = P.scene;
+    if constexpr (LDS_TAB) {
+        sc.lgeom = lgeom;
+        sc.lmat = lmat;
+    }
+
     const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
     const int x = tx * 8 + (lane & 7);
     const int y = P.row_begin + ty * 8 + (lane >> 3);
     const bool valid = (x < P.W) && (y < P.row_end);
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;  // GLOBAL pixel index
 
-    const SceneView sc = P.scene;
     PathCounters pc = {0, 0, 0};
     bool overflow = false;
     D3 acc = d3(0, 0, 0);
@@ -214,10 +119,11 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
             overflow = true;
     };
     auto pop = [&](int d) -> int { return (int)rec[(d < LDS_D ? d : LDS_D - 1) * 64 + lane]; };
+    const bool pow2 = P.inv_s != 0.0;  // wave-uniform
 
     while (n < P.total_samples) {
         D3 term;
-        bool cont = path_step(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
+        bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
         if (cont && depth > LDS_D) {  // records exhausted: stop the path, flag it (loud failure)
             cont = false;
             term = d3(0, 0, 0);
@@ -225,7 +131,9 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
         }
         if (!cont) {
             const D3 L = path_fold(sc, term, depth, pop);
-            D3 cal = ((L / P.dSS) / P.dSS) / P.dS;  // :240
+            // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
+            // power-of-two divisors are applied as multiplications.
+            const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
             acc = acc + d3(clamp01(cal.x), clamp01(cal.y), clamp01(cal.z));  // :241-242
             ++n;
             if (++s_in_sub == P.S) {
@@ -303,14 +211,16 @@ __global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParam
     };
     auto pop = [&](int d) -> int { return (int)P.scratch[(size_t)d * P.n_rays + i]; };
     D3 term;
-    while (path_step(P.scene, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push)) {
+    SceneGlobal sc;
+    sc.v = P.scene;
+    while (path_step<MathRef, 1>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push)) {
         if (depth >= RAY_MAX_DEPTH) {
             overflow = true;
             term = d3(0, 0, 0);
             break;
         }
     }
-    const D3 L = path_fold(P.scene, term, depth, pop);
+    const D3 L = path_fold(sc, term, depth, pop);
     P.out[i * 3] = L.x;
     P.out[i * 3 + 1] = L.y;
     P.out[i * 3 + 2] = L.z;
@@ -333,12 +243,12 @@ __global__ __launch_bounds__(64) void intersect_pairs_kernel(const double4* __re
     const D3 d = d3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     const double4 g = geom[i];
     double t;
-    const bool hit = sphere_test(g, o, d, t);
+    const bool hit = sphere_test<MathRef>(g, o, d, t);
     out_hit[i] = hit ? 1 : 0;
     if (hit) {
         out_t[i] = t;
         if (mode != RTM_MODE_LITERAL) {  // D2: literal mode never delivers the normal
-            const D3 nrm = sphere_normal(g, o + d * t);
+            const D3 nrm = normalize((o + d * t) - d3(g.x, g.y, g.z));  // src/SettingData.cpp:214-215
             out_normal[i * 3] = nrm.x;
             out_normal[i * 3 + 1] = nrm.y;
             out_normal[i * 3 + 2] = nrm.z;
@@ -370,6 +280,10 @@ __global__ void math_probe_kernel(int op, const double* __restrict__ a, const do
         case 5: sincos(x, &s, &c); r = s; break;
         case 6: sincos(x, &s, &c); r = c; break;
         case 7: r = x * y + 1.0; break;  // must NOT be contracted to an fma
+        case 8: r = MathFast::sqrt64(x); break;
+        case 9: r = MathFast::div3(d3(x, x * 0.5, -x), y).x; break;
+        case 10: r = MathFast::div3(d3(1.0, x, 0.0), y).y; break;
+        case 11: r = MathFast::div3(d3(y, -0.0, x), y).z; break;
     }
     out[i] = r;
 }
@@ -523,7 +437,11 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
     return RTM_OK;
 }
 
-static const char* kVariantNames[] = {"tile8x8-regen-lds"};
+// variant 0 = auto (the fastest parity-validated kernel for the scene size)
+static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-u4",
+                                      "fast-math-global-scene-u4"};
+constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3;
+constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* variant_name(int v) { return (v >= 0 && v < num_variants()) ? kVariantNames[v] : nullptr; }
 
@@ -551,6 +469,11 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.rate = (float)(1.0 / (1 + st->super_samples));
     P.dSS = (double)st->super_samples;
     P.dS = (double)st->samples;
+    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (opt->variant != kVariantRef && is_pow2(st->samples) && is_pow2(st->super_samples)) {
+        P.inv_ss = 1.0 / P.dSS;  // exact
+        P.inv_s = 1.0 / P.dS;
+    }
     P.cam_org = D3{origin.x, origin.y, origin.z};
     P.ax = D3{cam_x.x * fovx, cam_x.y * fovx, cam_x.z * fovx};  // l_camX * fovx, :229
     P.by = D3{cam_y.x * fovy, cam_y.y * fovy, cam_y.z * fovy};  // l_camY * fovy, :230
@@ -558,14 +481,30 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.seed_mult = seed_multiplier(opt->seed);
 }
 
-template <typename RecT>
-static void launch_render(const RenderParams& P, unsigned grid, hipStream_t stream) {
+template <class M, bool LDS_TAB, int UNROLL, typename RecT>
+static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
+    const size_t tab = LDS_TAB ? (size_t)P.scene.n * 12 * sizeof(double) : 0;
     if (P.max_bounces >= 0 && P.max_bounces < 16)
-        render_tiles_kernel<RecT, 16><<<grid, 64, 0, stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else if (sizeof(RecT) == 1)
-        render_tiles_kernel<RecT, 128><<<grid, 64, 0, stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 128><<<grid, 64, tab + 128 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<RecT, 64><<<grid, 64, 0, stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 64><<<grid, 64, tab + 64 * 64 * sizeof(RecT), stream>>>(P);
+}
+
+static void launch_render(int variant, const RenderParams& P, unsigned grid, hipStream_t stream) {
+    const int n = P.scene.n;
+    if (variant == kVariantAuto) variant = (n <= kLdsTableMaxSpheres) ? kVariantFastLds : kVariantFastGlobal;
+    if (variant == kVariantFastLds && n > kLdsTableMaxSpheres) variant = kVariantFastGlobal;
+    if (variant == kVariantRef) {
+        if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
+        else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
+    } else if (variant == kVariantFastLds) {
+        launch_render_depth<MathFast, true, 4, uint8_t>(P, grid, stream);
+    } else {
+        if (n <= 256) launch_render_depth<MathFast, false, 4, uint8_t>(P, grid, stream);
+        else launch_render_depth<MathFast, false, 4, uint32_t>(P, grid, stream);
+    }
 }
 
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
@@ -600,10 +539,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventCreate(&ev1));
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
-    if (n <= 256)
-        launch_render<uint8_t>(P, grid, stream);
-    else
-        launch_render<uint32_t>(P, grid, stream);
+    launch_render(opt->variant, P, grid, stream);
     RTM_HIP_CHECK(hipGetLastError());
     if (stats) {
         RTM_HIP_CHECK(hipEventRecord(ev1, stream));

@@ -74,6 +74,36 @@ def test_device_primitives_vs_host_libm(rtm):
     assert np.array_equal(_probe(rtm, 4, r1), _probe(rtm, 6, r1))
 
 
+def test_fast_math_is_bit_identical(rtm):
+    """MathFast (shared-reciprocal division, unscaled sqrt; rtm_path.h) must return the bits of the
+    compiler's IEEE division / sqrt for every operand class, including the ones that take its
+    wave-uniform fallback."""
+    rng = np.random.default_rng(21)
+    n = 1 << 22
+    # sqrt: moderate, tiny (< 2^-767: scaled path), zero, inf, nan, negative
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, n), rng.uniform(0, 1, n), 2.0 ** rng.uniform(-1070, -700, 4096),
+                        [0.0, -0.0, np.inf, np.nan, -1.0, 5e-324, 2.0 ** -767, np.nextafter(2.0 ** -767, 0), 1.0, 4.0]])
+    with np.errstate(invalid="ignore"):
+        want = np.sqrt(x)
+    got, ref = _probe(rtm, 8, x), _probe(rtm, 0, x)
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(got.view(np.uint64)[:-6], ref.view(np.uint64)[:-6])
+    assert np.array_equal(got, want, equal_nan=True)
+    # division by a float-valued denominator (what Normalize does), numerators of every class
+    yf = np.concatenate([(10.0 ** rng.uniform(-6, 6, n)).astype(np.float32),
+                         np.array([0.0, np.inf, 1e-45, 1.0, 3.0, np.float32(1e38), np.float32(1e-38)], dtype=np.float32)])
+    y = yf.astype(np.float64) * rng.choice([-1.0, 1.0], yf.size)
+    xs = np.concatenate([10.0 ** rng.uniform(-12, 8, y.size - 64) * rng.choice([-1.0, 1.0], y.size - 64),
+                         [0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 1e-300, 1e300, 1e-200, 1e200, 2.0 ** -401,
+                          2.0 ** -400, 2.0 ** 400, 2.0 ** 401, 1.0] * 4])
+    rng.shuffle(xs)
+    with np.errstate(all="ignore"):
+        for op, num in ((9, xs), (10, xs), (11, xs)):
+            got = _probe(rtm, op, xs, y)
+            want = num / y
+            same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+            assert same.all(), (op, xs[~same][:5], y[~same][:5], got[~same][:5], want[~same][:5])
+
+
 def test_device_rng_matches_host_and_oracle(rtm, oracle):
     out = np.zeros((64, 40), dtype=np.float64)
     rtm._lib.check(rtm.lib().rtm_rng_batch(0x5EED, 1000, 64, 3, 40, out.ctypes.data), "rng_batch")
@@ -149,8 +179,8 @@ def test_path_tracing_batch_vs_oracle(rtm, oracle, scene, max_bounces):
     assert worst <= PIXEL_TOL
 
 
-def _gpu_image(rtm, data, mode, max_bounces, seed, want=("f64", "f32", "u8"), rows=None):
-    r = rtm.Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed)
+def _gpu_image(rtm, data, mode, max_bounces, seed, want=("f64", "f32", "u8"), rows=None, variant=0):
+    r = rtm.Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, variant=variant)
     rb, re = rows if rows else (0, data.height)
     out, stats = r.render_rows(rb, re, want=want)
     return out, stats
@@ -194,6 +224,27 @@ def test_render_literal_matches_reference_golden_hashes(rtm, oracle):
         assert float(out["f64"].sum()) == case["sum"] and int((out["f64"] != 0).sum()) == case["nonzero"]
         if "white_pixels_rgb8" in case:
             assert int((out["u8"].reshape(-1, 3) == 255).all(axis=1).sum()) == case["white_pixels_rgb8"]
+
+
+@pytest.mark.parametrize("scene,mode,max_bounces", [("cornellBoxSetting.json", "repaired", 8),
+                                                    ("cornellBoxSetting.json", "repaired", -1),
+                                                    ("cornellBoxSetting.json", "literal", -1),
+                                                    ("simpleSetting2.json", "repaired", -1),
+                                                    ("settingData.json", "repaired", 3)])
+def test_kernel_variants_are_bit_identical(rtm, oracle, scene, mode, max_bounces):
+    """Every kernel variant (reference math / fast math, global / LDS scene tables, non-power-of-
+    two and power-of-two sample counts) produces the same bits and the same counters."""
+    data = rtm.LoadData(oracle.scene_path(scene), literal_loader=(mode == "literal")).data
+    for (w, h, s, ss) in ((200, 120, 8, 2), (61, 37, 5, 3)):
+        data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+        names = [rtm.lib().rtm_variant_name(v).decode() for v in range(rtm.lib().rtm_num_variants())]
+        ref, ref_stats = _gpu_image(rtm, data, mode, max_bounces, 0x5EED, want=("f64", "u8"), variant=1)
+        for v in range(len(names)):
+            out, st = _gpu_image(rtm, data, mode, max_bounces, 0x5EED, want=("f64", "u8"), variant=v)
+            assert np.array_equal(out["f64"].view(np.uint64), ref["f64"].view(np.uint64)), names[v]
+            assert np.array_equal(out["u8"], ref["u8"])
+            assert {k: st[k] for k in ("samples", "casts", "bounces", "draws")} == \
+                {k: ref_stats[k] for k in ("samples", "casts", "bounces", "draws")}, names[v]
 
 
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
