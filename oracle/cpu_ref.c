@@ -247,6 +247,7 @@ static inline uint64_t smfin64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+/* pixel key: one 64-bit mix per pixel; sample key: one 32-bit mix; draw: two 32-bit mixes */
 typedef struct rng_stream {
     uint32_t k0, k1, index;
     rtmo_counters* c;
@@ -256,10 +257,10 @@ static inline uint64_t seed_multiplier(uint64_t seed) {
     return smfin64(seed + 0x9E3779B97F4A7C15ull) | 1ull;
 }
 static inline void stream_init(rng_stream* s, uint64_t seed_mult, uint32_t pixel, uint32_t sample) {
-    const uint64_t ctr = ((uint64_t)pixel << 32) | (uint64_t)sample;
-    const uint64_t z = smfin64((ctr + 1ull) * seed_mult);
-    s->k0 = (uint32_t)z;
-    s->k1 = (uint32_t)(z >> 32);
+    const uint64_t z = smfin64(((uint64_t)pixel + 1ull) * seed_mult);
+    const uint32_t p0 = (uint32_t)z, p1 = (uint32_t)(z >> 32);
+    s->k0 = mix32(p0 + sample * 0x9E3779B9u);
+    s->k1 = p1 ^ (sample * 0x85EBCA6Bu);
     s->index = 0;
 }
 static inline double stream_u01(uint32_t k0, uint32_t k1, uint32_t index) {

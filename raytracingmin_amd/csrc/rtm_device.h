@@ -52,23 +52,37 @@ __host__ __device__ __forceinline__ uint64_t smfin64(uint64_t z) {
 __host__ __device__ __forceinline__ uint64_t seed_multiplier(uint64_t seed) {
     return smfin64(seed + 0x9E3779B97F4A7C15ull) | 1ull;
 }
-struct RngStream {
-    uint32_t k0, k1, index;
+// Keying: one 64-bit mix per PIXEL, one 32-bit mix per SAMPLE, two 32-bit mixes per DRAW.
+//   pixel key   (p0, p1) = halves of smfin64((pixel + 1) * seed_mult)
+//   sample key  k0 = mix32(p0 + sample * 0x9E3779B9), k1 = p1 ^ (sample * 0x85EBCA6B)
+//   draw j      bits = mix32(mix32(k0 + j * 0x9E3779B9) ^ k1);  u = (2 * (bits >> 9) + 1) * 2^-24
+struct RngPixelKey {
+    uint32_t p0, p1;
 };
-__host__ __device__ __forceinline__ RngStream rng_open(uint64_t seed_mult, uint32_t pixel,
-                                                       uint32_t sample) {
-    const uint64_t ctr = ((uint64_t)pixel << 32) | (uint64_t)sample;
-    const uint64_t z = smfin64((ctr + 1ull) * seed_mult);
-    return RngStream{(uint32_t)z, (uint32_t)(z >> 32), 0u};
+struct RngStream {
+    uint32_t ctr, k1;  // ctr = k0 + index * 0x9E3779B9
+};
+__host__ __device__ __forceinline__ RngPixelKey rng_pixel_key(uint64_t seed_mult, uint32_t pixel) {
+    const uint64_t z = smfin64(((uint64_t)pixel + 1ull) * seed_mult);
+    return RngPixelKey{(uint32_t)z, (uint32_t)(z >> 32)};
 }
-__host__ __device__ __forceinline__ double rng_u01_at(uint32_t k0, uint32_t k1, uint32_t index) {
-    uint32_t x = mix32(k0 + index * 0x9E3779B9u);
-    x = mix32(x ^ k1);
+__host__ __device__ __forceinline__ RngStream rng_open(RngPixelKey pk, uint32_t sample) {
+    return RngStream{mix32(pk.p0 + sample * 0x9E3779B9u), pk.p1 ^ (sample * 0x85EBCA6Bu)};
+}
+__host__ __device__ __forceinline__ double rng_bits_to_u01(uint32_t x) {
     // 23 random bits -> odd multiple of 2^-24: never 0 or 1, exact in fp32 and fp64
     return (double)(2u * (x >> 9) + 1u) * (1.0 / 16777216.0);
 }
 __host__ __device__ __forceinline__ double rng_next(RngStream& s) {
-    return rng_u01_at(s.k0, s.k1, s.index++);
+    const uint32_t x = mix32(mix32(s.ctr) ^ s.k1);
+    s.ctr += 0x9E3779B9u;
+    return rng_bits_to_u01(x);
+}
+__host__ __device__ __forceinline__ double rng_u01_at(uint64_t seed_mult, uint32_t pixel, uint32_t sample,
+                                                      uint32_t index) {
+    RngStream s = rng_open(rng_pixel_key(seed_mult, pixel), sample);
+    s.ctr += index * 0x9E3779B9u;
+    return rng_next(s);
 }
 
 }  // namespace rtm

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
     D3 pdir = primary_dir(P, x, y, 1, 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
-    RngStream rng = rng_open(P.seed_mult, pixel, 0u);
+    const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
+    RngStream rng = rng_open(pkey, 0u);
 
     auto push = [&](int d, int id) {
         if (d < LDS_D)
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
             org = P.cam_org;
             dir = pdir;
             depth = 0;
-            rng = rng_open(P.seed_mult, pixel, n);
+            rng = rng_open(pkey, n);
         }
     }
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParam
     if (i >= P.n_rays) return;
     D3 org = d3(P.org[i * 3], P.org[i * 3 + 1], P.org[i * 3 + 2]);
     D3 dir = d3(P.dir[i * 3], P.dir[i * 3 + 1], P.dir[i * 3 + 2]);
-    RngStream rng = rng_open(P.seed_mult, (uint32_t)i, 0u);
+    RngStream rng = rng_open(rng_pixel_key(P.seed_mult, (uint32_t)i), 0u);
     PathCounters pc = {0, 0, 0};
     int depth = 0;
     bool overflow = false;
@@ -260,7 +261,7 @@ __global__ void rng_batch_kernel(uint64_t seed_mult, uint32_t pixel0, uint32_t n
                                  uint32_t sample, uint32_t n_draws, double* __restrict__ out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
-    RngStream s = rng_open(seed_mult, pixel0 + p, sample);
+    RngStream s = rng_open(rng_pixel_key(seed_mult, pixel0 + p), sample);
     for (uint32_t k = 0; k < n_draws; ++k) out[(size_t)p * n_draws + k] = rng_next(s);
 }
 
@@ -705,8 +706,7 @@ int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample
 }
 
 double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index) {
-    const RngStream s = rng_open(seed_multiplier(seed), pixel, sample);
-    return rng_u01_at(s.k0, s.k1, index);
+    return rng_u01_at(seed_multiplier(seed), pixel, sample, index);
 }
 
 int math_probe(int op, const double* a, const double* b, size_t n, double* out) {

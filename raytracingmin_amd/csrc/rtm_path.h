@@ -38,8 +38,11 @@ struct MathFast {
         return (unsigned)(e + 400) <= 800u;
     }
     static __device__ __forceinline__ double sqrt64(double x) {
-        const bool needs_scaling = (x < 0x1p-767) && (x != 0.0);  // negative or tiny; NaN: false
-        if (__builtin_amdgcn_ballot_w64(needs_scaling) != 0) return ::sqrt(x);
+        // Fast lanes: positive, finite, >= 2^-767 (no pre-scaling, no 0/inf fix-up needed) or
+        // negative (rsq gives the NaN IEEE asks for).  +-0, tiny, +inf, +NaN take the full path.
+        const unsigned h = (unsigned)__double2hiint(x);
+        const bool fast = (h - 0x10000000u < 0x6FF00000u) || (h > 0x80000000u);
+        if (__builtin_amdgcn_ballot_w64(!fast) != 0) return ::sqrt(x);
         const double y = __builtin_amdgcn_rsq(x);
         const double s0 = x * y, h0 = 0.5 * y;
         const double r0 = __builtin_fma(-h0, s0, 0.5);
@@ -47,8 +50,7 @@ struct MathFast {
         const double d0 = __builtin_fma(-s1, s1, x);
         const double s2 = __builtin_fma(d0, h1, s1);
         const double d1 = __builtin_fma(-s2, s2, x);
-        const double ret = __builtin_fma(d1, h1, s2);
-        return __builtin_amdgcn_class(x, 0x260 /* +-0, +inf */) ? x : ret;
+        return __builtin_fma(d1, h1, s2);
     }
     static __device__ __forceinline__ D3 div3(D3 a, double y) {
         const bool ok = moderate(y) && moderate(a.x) && moderate(a.y) && moderate(a.z);
@@ -128,7 +130,7 @@ struct SceneLds {
 };
 
 // ------------------------------------------------------------------------------------------------
-// src/SettingData.cpp:197-226 without the normal: returns hit and t.
+// src/SettingData.cpp:197-226 without the normal: returns hit and t (the literal statement order).
 template <class M>
 __device__ __forceinline__ bool sphere_test(const double4 g, const D3 org, const D3 dir, double& t) {
     const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // :198
@@ -141,6 +143,30 @@ __device__ __forceinline__ bool sphere_test(const double4 g, const D3 org, const
     if (t1 < min_value && t2 < min_value) return false;        // :209
     t = (t1 > 0.001) ? t1 : t2;                                // :212-223
     return true;
+}
+
+// Intersect (src/SettingData.cpp:197-226) fused with the caller's acceptance test
+// (src/Renderer.cpp:67: hit && t < dis && t > 0), select-only form.  Equivalence with the
+// statement order above, with m = 1e-5f and sq >= 0 or NaN (so t2 >= t1):
+//   t1 > 0.001          : Intersect returns t = t1 (> m > 0); accepted iff t1 < dis.
+//   t1 <= 0.001         : Intersect returns t = t2 unless (t1 < m && t2 < m); since t2 >= t1 that is
+//                         "t2 >= m", and then t2 > 0 holds; accepted iff m <= t2 < dis.
+//   D4 < 0              : the policy sqrt yields NaN, t is NaN, "t < dis" is false: no hit.
+//   NaN ray (literal)   : D4 NaN, Intersect returns true with t NaN, the caller's t < dis fails.
+// Hence accept == (t < dis) && !(t < m) with t = t1 > 0.001 ? t1 : t2, in every case.
+template <class M>
+__device__ __forceinline__ void sphere_update(const double4 g, const D3 org, const D3 dir, const int i,
+                                              double& dis, int& hit_object) {
+    const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // :198
+    const double b = dot(p_o, dir);                            // :199
+    const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200
+    if (__builtin_amdgcn_ballot_w64(D4 >= 0.0) == 0) return;   // whole wave misses (or NaN rays)
+    const double sq = M::sqrt64(D4);                           // :205
+    const double t1 = b - sq, t2 = b + sq;
+    const double t = (t1 > 0.001) ? t1 : t2;
+    const bool accept = (t < dis) && !(t < (double)1e-5f);
+    dis = accept ? t : dis;
+    hit_object = accept ? i : hit_object;
 }
 
 // src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
@@ -165,15 +191,8 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
 #pragma unroll
             for (int k = 0; k < UNROLL; ++k) g[k] = sc.geom_uniform(i0 + k < n ? i0 + k : n - 1);
 #pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                if (i0 + k < n) {  // wave-uniform
-                    double t;
-                    if (sphere_test<M>(g[k], org, dir, t) && t < dis && t > 0) {
-                        dis = t;
-                        hit_object = i0 + k;
-                    }
-                }
-            }
+            for (int k = 0; k < UNROLL; ++k)
+                if (i0 + k < n) sphere_update<M>(g[k], org, dir, i0 + k, dis, hit_object);  // uniform
         }
     }
     return hit_object;
