@@ -104,8 +104,10 @@ const char* rtm_variant_name(int variant);
  * out_f32 is the same value rounded to float (the float3 accumulation buffer); out_u8 is the
  * reference's 8-bit quantisation (src/Renderer.cpp:251-254).
  * Asynchronous on `stream` unless stats != NULL (then it synchronises the stream to read the
- * counters and timing).  Scene arrays are HOST pointers (tiny for shipped scenes) unless
- * spheres_on_device != 0. */
+ * counters and timing).  Hit records of paths deeper than the on-chip levels spill to a pooled
+ * buffer (capacity: 992 bounces per path, 65536 such paths per launch); exceeding it is reported as
+ * RTM_ERR_UNSUPPORTED, which — like the counters — can only be observed when stats != NULL.
+ * Scene arrays are HOST pointers (tiny for shipped scenes) unless spheres_on_device != 0. */
 int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
                       int spheres_on_device, const rtm_options* options, double* out_f64_dev,
                       float* out_f32_dev, uint8_t* out_u8_dev, void* stream, rtm_stats* stats);

@@ -52,6 +52,50 @@ struct RenderParams {
     float* __restrict__ out32;
     uint8_t* __restrict__ out8;
     unsigned long long* __restrict__ counters;  // casts, bounces, draws, overflow flag
+    // deep-path record pool (only when a path may run deeper than the LDS record stack)
+    unsigned char* __restrict__ pool;       // pool_slots x kPoolLevels records
+    unsigned* __restrict__ pool_next;       // bump allocator
+    unsigned pool_slots;
+};
+
+constexpr int kPoolLevels = 960;  // records per pool slot beyond the LDS levels
+
+// Per-lane stack of hit records: the first LDS_D levels live in LDS ([depth][lane]); a lane whose
+// path runs deeper takes, once, a slot of kPoolLevels records from a global pool.  Exhausting the
+// pool or the slot raises the overflow flag and the call fails with RTM_ERR_UNSUPPORTED.
+template <typename RecT, int LDS_D>
+struct RecordStack {
+    RecT* lds;  // this wave's [LDS_D][64]
+    int lane;
+    const RenderParams* P;
+    int slot = -1;
+    bool overflow = false;
+    __device__ __forceinline__ RecT* slot_ptr() {
+        if (slot < 0) {
+            const unsigned got = P->pool ? atomicAdd(P->pool_next, 1u) : 0xFFFFFFFFu;
+            if (got >= P->pool_slots) {
+                overflow = true;
+                return nullptr;
+            }
+            slot = (int)got;
+        }
+        return reinterpret_cast<RecT*>(P->pool) + (size_t)slot * kPoolLevels;
+    }
+    __device__ __forceinline__ void push(int d, int id) {
+        if (d < LDS_D) {
+            lds[d * 64 + lane] = (RecT)id;
+        } else if (d - LDS_D < kPoolLevels) {
+            if (RecT* p = slot_ptr()) p[d - LDS_D] = (RecT)id;
+        } else {
+            overflow = true;
+        }
+    }
+    __device__ __forceinline__ int pop(int d) {
+        if (d < LDS_D) return (int)lds[d * 64 + lane];
+        if (slot < 0 || d - LDS_D >= kPoolLevels) return 0;  // only after an overflow: image is discarded
+        return (int)(reinterpret_cast<const RecT*>(P->pool) + (size_t)slot * kPoolLevels)[d - LDS_D];
+    }
+    static constexpr int kCapacity = LDS_D + kPoolLevels;
 };
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
@@ -65,6 +109,30 @@ __device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsign
     unsigned long long s = v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+}
+
+// src/Renderer.cpp:246-254: image[] += acc; optional float3 / 8-bit views of the same pixel
+__device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, int x, int y, D3 acc) {
+    if (!valid) return;
+    const size_t o = ((size_t)(y - P.row_begin) * P.W + x) * 3;
+    const double r = 0.0 + acc.x, g = 0.0 + acc.y, b = 0.0 + acc.z;  // :246-248
+    if (P.out64) {
+        P.out64[o] = r;
+        P.out64[o + 1] = g;
+        P.out64[o + 2] = b;
+    }
+    if (P.out32) {
+        P.out32[o] = (float)r;
+        P.out32[o + 1] = (float)g;
+        P.out32[o + 2] = (float)b;
+    }
+    if (P.out8) {  // :253: (unsigned char)255 * std::min(v, 1.0), truncation
+        const double q[3] = {r, g, b};
+        for (int c = 0; c < 3; ++c) {
+            const double v = 255 * ((1.0 < q[c]) ? 1.0 : q[c]);
+            P.out8[o + c] = (v >= 0.0 && v < 256.0) ? (uint8_t)v : (uint8_t)0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,7 +170,7 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;  // GLOBAL pixel index
 
     PathCounters pc = {0, 0, 0};
-    bool overflow = false;
+    RecordStack<RecT, LDS_D> stack{rec, lane, &P};
     D3 acc = d3(0, 0, 0);
 
     unsigned n = valid ? 0u : P.total_samples;  // sample index ((sx-1)*SS + (sy-1))*S + s
@@ -113,22 +181,17 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
     const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
     RngStream rng = rng_open(pkey, 0u);
 
-    auto push = [&](int d, int id) {
-        if (d < LDS_D)
-            rec[d * 64 + lane] = (RecT)id;
-        else
-            overflow = true;
-    };
-    auto pop = [&](int d) -> int { return (int)rec[(d < LDS_D ? d : LDS_D - 1) * 64 + lane]; };
+    auto push = [&](int d, int id) { stack.push(d, id); };
+    auto pop = [&](int d) -> int { return stack.pop(d); };
     const bool pow2 = P.inv_s != 0.0;  // wave-uniform
 
     while (n < P.total_samples) {
         D3 term;
         bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
-        if (cont && depth > LDS_D) {  // records exhausted: stop the path, flag it (loud failure)
+        if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
             cont = false;
             term = d3(0, 0, 0);
-            depth = LDS_D;
+            depth = 0;
         }
         if (!cont) {
             const D3 L = path_fold(sc, term, depth, pop);
@@ -149,32 +212,130 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
         }
     }
 
-    if (valid) {
-        const size_t o = ((size_t)(y - P.row_begin) * P.W + x) * 3;
-        const double r = 0.0 + acc.x, g = 0.0 + acc.y, b = 0.0 + acc.z;  // :246-248
-        if (P.out64) {
-            P.out64[o] = r;
-            P.out64[o + 1] = g;
-            P.out64[o + 2] = b;
-        }
-        if (P.out32) {
-            P.out32[o] = (float)r;
-            P.out32[o + 1] = (float)g;
-            P.out32[o + 2] = (float)b;
-        }
-        if (P.out8) {  // :253: (unsigned char)255 * std::min(v, 1.0), truncation
-            const double q[3] = {r, g, b};
-            for (int c = 0; c < 3; ++c) {
-                const double v = 255 * ((1.0 < q[c]) ? 1.0 : q[c]);
-                P.out8[o + c] = (v >= 0.0 && v < 256.0) ? (uint8_t)v : (uint8_t)0;
-            }
-        }
-    }
+    store_pixel(P, valid, x, y, acc);
     if (P.counters) {
         wave_add_counter(P.counters + 0, pc.casts);
         wave_add_counter(P.counters + 1, pc.bounces);
         wave_add_counter(P.counters + 2, pc.draws);
-        if (overflow) atomicOr(P.counters + 3, 1ull);
+        if (stack.overflow) atomicOr(P.counters + 3, 1ull);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large scenes (BASELINE configs[4]: 100 k spheres): the sphere list is streamed HBM/L2 -> LDS in
+// tiles of TILE spheres by the whole 256-thread workgroup with coalesced 16-byte loads (double
+// buffered: the next tile is fetched into registers while the current one is tested), and every lane
+// of the four waves reads the same LDS address per sphere (broadcast, conflict-free).  One
+// workgroup = four 8x8 pixel tiles side by side; all lanes of the block run the nearest-hit loop in
+// lock-step (it contains the barriers), shading and path bookkeeping are per lane as in
+// render_tiles_kernel.  Index order and strict < are preserved across tiles, so the lowest index
+// still wins exact ties.
+template <class M, typename RecT, int LDS_D, int TILE>
+__global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double2* tile_buf = reinterpret_cast<double2*>(lds_raw);            // 2 x TILE x 2 double2
+    RecT* rec_all = reinterpret_cast<RecT*>(tile_buf + 2 * TILE * 2);  // 4 waves x LDS_D x 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    RecT* rec = rec_all + wave * LDS_D * 64;
+    constexpr int CHUNKS = TILE * 2 / 256;  // 16-byte chunks per thread per tile
+
+    SceneGlobal sc;
+    sc.v = P.scene;
+    const int n = P.scene.n;
+    const int n_tiles = (n + TILE - 1) / TILE;
+    const double2* gsrc = reinterpret_cast<const double2*>(P.scene.geom);
+    const int n_chunks = n * 2;
+
+    const int tiles_x4 = (P.tiles_x + 3) / 4;
+    const int tx = (blockIdx.x % tiles_x4) * 4 + wave, ty = blockIdx.x / tiles_x4;
+    const int x = tx * 8 + (lane & 7);
+    const int y = P.row_begin + ty * 8 + (lane >> 3);
+    const bool valid = (x < P.W) && (y < P.row_end);
+    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+
+    PathCounters pc = {0, 0, 0};
+    RecordStack<RecT, LDS_D> stack{rec, lane, &P};
+    D3 acc = d3(0, 0, 0);
+    unsigned ns = valid ? 0u : P.total_samples;
+    int s_in_sub = 0, sub = 0;
+    D3 pdir = primary_dir(P, x, y, 1, 1);
+    D3 org = P.cam_org, dir = pdir;
+    int depth = 0;
+    const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
+    RngStream rng = rng_open(pkey, 0u);
+    auto push = [&](int d, int id) { stack.push(d, id); };
+    auto pop = [&](int d) -> int { return stack.pop(d); };
+    const bool pow2 = P.inv_s != 0.0;
+
+    while (__syncthreads_or(ns < P.total_samples)) {
+        // ---- nearest hit over the whole scene, tile by tile (src/Renderer.cpp:62-72) ----
+        double dis = DBL_MAX;
+        int id = -1;
+        if (n_tiles > 0) {
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {
+                const int c = k * 256 + tid;
+                tile_buf[c] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < n_tiles; ++t) {
+            double2 pre[CHUNKS];
+            const bool more = (t + 1 < n_tiles);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < CHUNKS; ++k) {
+                    const int c = (t + 1) * TILE * 2 + k * 256 + tid;
+                    pre[k] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
+                }
+            }
+            const double2* cur = tile_buf + (t & 1) * TILE * 2;
+            const int base = t * TILE;
+            const int cnt = (n - base < TILE) ? (n - base) : TILE;
+#pragma unroll 4
+            for (int j = 0; j < cnt; ++j) {
+                const double2 a = cur[2 * j], b = cur[2 * j + 1];  // same address in every lane
+                sphere_update<M>(double4{a.x, a.y, b.x, b.y}, org, dir, base + j, dis, id);
+            }
+            if (more) {
+                double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
+#pragma unroll
+                for (int k = 0; k < CHUNKS; ++k) nxt[k * 256 + tid] = pre[k];
+            }
+            __syncthreads();
+        }
+        // ---- shade / bookkeeping, per lane ----
+        if (ns < P.total_samples) {
+            D3 term;
+            bool cont = path_shade<M>(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
+            if (cont && stack.overflow) {
+                cont = false;
+                term = d3(0, 0, 0);
+                depth = 0;
+            }
+            if (!cont) {
+                const D3 L = path_fold(sc, term, depth, pop);
+                const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
+                acc = acc + d3(clamp01(cal.x), clamp01(cal.y), clamp01(cal.z));
+                ++ns;
+                if (++s_in_sub == P.S) {
+                    s_in_sub = 0;
+                    ++sub;
+                    if (ns < P.total_samples) pdir = primary_dir(P, x, y, sub / P.SS + 1, sub % P.SS + 1);
+                }
+                org = P.cam_org;
+                dir = pdir;
+                depth = 0;
+                rng = rng_open(pkey, ns);
+            }
+        }
+    }
+    store_pixel(P, valid, x, y, acc);
+    if (P.counters) {
+        wave_add_counter(P.counters + 0, pc.casts);
+        wave_add_counter(P.counters + 1, pc.bounces);
+        wave_add_counter(P.counters + 2, pc.draws);
+        if (stack.overflow) atomicOr(P.counters + 3, 1ull);
     }
 }
 
@@ -431,6 +592,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
         set_last_error("image, sample or scene count exceeds 32-bit indexing");
         return RTM_ERR_UNSUPPORTED;
     }
+    if (opt->max_bounces > 32 + kPoolLevels) {
+        set_last_error("max_bounces exceeds the hit-record capacity (992); use -1 for unlimited");
+        return RTM_ERR_UNSUPPORTED;
+    }
     if (opt->variant < 0 || opt->variant >= num_variants()) {
         set_last_error("unknown kernel variant");
         return RTM_ERR_INVALID_ARGUMENT;
@@ -440,8 +605,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 
 // variant 0 = auto (the fastest parity-validated kernel for the scene size)
 static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-u4",
-                                      "fast-math-global-scene-u4"};
-constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3;
+                                      "fast-math-global-scene-u4", "fast-math-lds-scene-tiles"};
+constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
+              kVariantSceneTiled = 4;
+constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* variant_name(int v) { return (v >= 0 && v < num_variants()) ? kVariantNames[v] : nullptr; }
@@ -482,20 +649,44 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.seed_mult = seed_multiplier(opt->seed);
 }
 
+// LDS record levels: 16 when the cap guarantees depth < 16; otherwise 64 (u8) / 32 (u32) levels in
+// LDS plus the global pool for the rare deeper path.
+template <typename RecT>
+constexpr int deep_lds_levels() { return sizeof(RecT) == 1 ? 64 : 32; }
+static bool needs_pool(const RenderParams& P) { return !(P.max_bounces >= 0 && P.max_bounces < 16); }
+
 template <class M, bool LDS_TAB, int UNROLL, typename RecT>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = LDS_TAB ? (size_t)P.scene.n * 12 * sizeof(double) : 0;
-    if (P.max_bounces >= 0 && P.max_bounces < 16)
+    constexpr int DEEP = deep_lds_levels<RecT>();
+    if (!needs_pool(P))
         render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
-    else if (sizeof(RecT) == 1)
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 128><<<grid, 64, tab + 128 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 64><<<grid, 64, tab + 64 * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
-static void launch_render(int variant, const RenderParams& P, unsigned grid, hipStream_t stream) {
+template <typename RecT>
+static void launch_scene_tiled(const RenderParams& P, unsigned tiles_y, hipStream_t stream) {
+    const unsigned grid = (unsigned)((P.tiles_x + 3) / 4) * tiles_y;
+    const size_t tile_bytes = 2 * (size_t)kSceneTile * 32;
+    constexpr int DEEP = deep_lds_levels<RecT>();
+    if (!needs_pool(P))
+        render_scene_tiled_kernel<MathFast, RecT, 16, kSceneTile>
+            <<<grid, 256, tile_bytes + 4 * 16 * 64 * sizeof(RecT), stream>>>(P);
+    else
+        render_scene_tiled_kernel<MathFast, RecT, DEEP, kSceneTile>
+            <<<grid, 256, tile_bytes + 4 * DEEP * 64 * sizeof(RecT), stream>>>(P);
+}
+
+static void launch_render(int variant, const RenderParams& P, unsigned grid, unsigned tiles_y,
+                          hipStream_t stream) {
     const int n = P.scene.n;
-    if (variant == kVariantAuto) variant = (n <= kLdsTableMaxSpheres) ? kVariantFastLds : kVariantFastGlobal;
+    if (variant == kVariantAuto) variant = (n <= kLdsTableMaxSpheres) ? kVariantFastLds : kVariantSceneTiled;
+    if (variant == kVariantSceneTiled) {
+        if (n <= 256) launch_scene_tiled<uint8_t>(P, tiles_y, stream);
+        else launch_scene_tiled<uint32_t>(P, tiles_y, stream);
+        return;
+    }
     if (variant == kVariantFastLds && n > kLdsTableMaxSpheres) variant = kVariantFastGlobal;
     if (variant == kVariantRef) {
         if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
@@ -531,6 +722,24 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     P.out32 = out32;
     P.out8 = out8;
     P.counters = ds.counters;
+    // deep-path record pool: 65536 slots x 960 records (60 MiB u8 / 240 MiB u32), stream-ordered
+    unsigned char* pool = nullptr;
+    if (needs_pool(P)) {
+        const size_t rec_bytes = (n <= 256) ? 1 : 4;
+        P.pool_slots = 65536;
+        const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
+        RTM_HIP_CHECK(hipMallocAsync((void**)&pool, pool_bytes + 64, stream));
+        P.pool = pool;
+        P.pool_next = reinterpret_cast<unsigned*>(pool + pool_bytes);
+        RTM_HIP_CHECK(hipMemsetAsync(P.pool_next, 0, sizeof(unsigned), stream));
+    }
+    struct PoolFree {
+        unsigned char* p;
+        hipStream_t s;
+        ~PoolFree() {
+            if (p) (void)hipFreeAsync(p, s);
+        }
+    } pool_free{pool, stream};
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
 
@@ -540,7 +749,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventCreate(&ev1));
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
-    launch_render(opt->variant, P, grid, stream);
+    launch_render(opt->variant, P, grid, tiles_y, stream);
     RTM_HIP_CHECK(hipGetLastError());
     if (stats) {
         RTM_HIP_CHECK(hipEventRecord(ev1, stream));
@@ -557,7 +766,8 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         stats->draws = c[2];
         stats->kernel_ms = ms;
         if (c[3]) {
-            set_last_error("a path ran deeper than the hit-record capacity of this kernel");
+            set_last_error("a path ran deeper than the hit-record capacity (LDS levels + 960 pooled levels, "
+                           "65536 pooled paths per launch)");
             return RTM_ERR_UNSUPPORTED;
         }
     }

@@ -202,15 +202,14 @@ struct PathCounters {
     unsigned casts, bounces, draws;
 };
 
-// One PathTracing invocation (src/Renderer.cpp:57-117) on the flattened path.
-// Returns true when the path continues (org/dir/depth updated, hit id pushed through `push`);
-// false when it ended with `term` = the value the deepest invocation returned.
-template <class M, int UNROLL, class Scene, typename PushFn>
-__device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const int max_bounces,
-                                          D3& org, D3& dir, int& depth, RngStream& rng, D3& term,
-                                          PathCounters& pc, PushFn push) {
-    double dis;
-    const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+// The part of one PathTracing invocation (src/Renderer.cpp:57-117) after the nearest-hit loop:
+// `id`/`dis` are that loop's result.  Returns true when the path continues (org/dir/depth updated,
+// hit id pushed through `push`); false when it ended with `term` = the value the deepest invocation
+// returned.
+template <class M, class Scene, typename PushFn>
+__device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const double dis, const int mode,
+                                           const int max_bounces, D3& org, D3& dir, int& depth,
+                                           RngStream& rng, D3& term, PathCounters& pc, PushFn push) {
     pc.casts++;
     if (id < 0) {  // :116
         term = d3(0, 0, 0);
@@ -250,6 +249,16 @@ __device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const
     org = hit_point;
     dir = nd;
     return true;
+}
+
+// One PathTracing invocation: nearest-hit loop + shading.
+template <class M, int UNROLL, class Scene, typename PushFn>
+__device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const int max_bounces,
+                                          D3& org, D3& dir, int& depth, RngStream& rng, D3& term,
+                                          PathCounters& pc, PushFn push) {
+    double dis;
+    const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+    return path_shade<M>(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
 }
 
 // Fold the recursion back to front: L = colorKD * L_next + emission (src/Renderer.cpp:109).

@@ -247,6 +247,93 @@ def test_kernel_variants_are_bit_identical(rtm, oracle, scene, mode, max_bounces
                 {k: ref_stats[k] for k in ("samples", "casts", "bounces", "draws")}, names[v]
 
 
+def _stress(rtm, oracle, n, w, h, s):
+    data = rtm.make_stress_scene(n=n, seed=12345)
+    data.width, data.height, data.samples, data.superSamples = w, h, s, 1
+    st, arr, cn = data.to_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Sphere * max(cn, 1)).from_buffer_copy(bytes(arr))
+    return data, ost, oarr
+
+
+@pytest.mark.parametrize("n,w,h,s", [(300, 64, 40, 4), (3000, 48, 32, 4), (100_000, 32, 16, 2)])
+def test_stress_scene_vs_oracle(rtm, oracle, n, w, h, s):
+    """BASELINE configs[4] scene family: many small spheres, u32 hit records,
+    scene streamed per cast; lowest index must still win exact ties."""
+    data, ost, oarr = _stress(rtm, oracle, n, w, h, s)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=5, height=h))
+    base = None
+    for v in range(rtm.lib().rtm_num_variants()):
+        out, stats = _gpu_image(rtm, data, "repaired", 8, 5, want=("f64",), variant=v)
+        err = float(np.max(np.abs(out["f64"] - ref)))
+        print(f"stress n={n} variant {v}: max pixel delta {err:.3e}, casts/sample "
+              f"{stats['casts'] / stats['samples']:.3f}, kernel {stats['kernel_ms']:.1f} ms")
+        assert err <= PIXEL_TOL
+        assert (stats["casts"], stats["bounces"], stats["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"])
+        if base is None:
+            base = out["f64"]
+        assert np.array_equal(out["f64"].view(np.uint64), base.view(np.uint64))
+
+
+def test_coincident_spheres_lowest_index_wins(rtm, oracle):
+    """Exact ties (the literal Cornell scene has four coincident spheres): strict < keeps the
+    lowest index (src/Renderer.cpp:67), also across geometry batches."""
+    base = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    wall = base.object[1]
+    objs = []
+    for k in range(11):  # 11 coincident walls with different colours + the light
+        o = rtm.SphereObject(rtm.vec3(0, 0, 0), 50.0, rtm.Material(rtm.vec3(0.1 + 0.07 * k, 0.5, 0.9 - 0.07 * k), rtm.vec3(0, 0, 0)))
+        objs.append(o)
+    objs.insert(5, base.object[0])
+    data = rtm.SettingData(width=40, height=24, samples=4, superSamples=2, camera=base.camera, object=objs)
+    st, arr, n = data.to_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=6, seed=3, height=24))
+    for v in range(rtm.lib().rtm_num_variants()):
+        out, stats = _gpu_image(rtm, data, "repaired", 6, 3, want=("f64",), variant=v)
+        assert float(np.max(np.abs(out["f64"] - ref))) <= PIXEL_TOL
+        assert stats["casts"] == cnt["casts"]
+
+
+def _white_room(rtm, albedo, w=24, h=16, s=4):
+    cam = rtm.Camera(rtm.vec3(0, 0, -3), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.0)
+    room = rtm.SphereObject(rtm.vec3(0, 0, 0), 20.0, rtm.Material(rtm.vec3(albedo, albedo, albedo), rtm.vec3(0, 0, 0)))
+    lamp = rtm.SphereObject(rtm.vec3(0, 12, 0), 4.0, rtm.Material(rtm.vec3(0, 0, 0), rtm.vec3(3, 2, 1)))
+    return rtm.SettingData(width=w, height=h, samples=s, superSamples=1, camera=cam, object=[room, lamp])
+
+
+def test_deep_paths_use_record_pool(rtm, oracle):
+    """Unlimited recursion: paths far deeper than the LDS record levels (64) spill to the global
+    record pool and still fold exactly like the recursion."""
+    data = _white_room(rtm, 0.975)
+    st, arr, n = data.to_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=11, height=data.height))
+    assert cnt["max_depth"] > 80  # well past the 64 LDS levels
+    for v in range(rtm.lib().rtm_num_variants()):
+        out, stats = _gpu_image(rtm, data, "repaired", -1, 11, want=("f64",), variant=v)
+        assert float(np.max(np.abs(out["f64"] - ref))) <= PIXEL_TOL
+        assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"])
+    # a cap beyond the LDS levels goes through the pool too
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=100, seed=11, height=data.height))
+    out, stats = _gpu_image(rtm, data, "repaired", 100, 11, want=("f64",))
+    assert float(np.max(np.abs(out["f64"] - ref))) <= PIXEL_TOL and stats["casts"] == cnt["casts"]
+
+
+def test_record_overflow_fails_loudly(rtm):
+    """A path deeper than LDS + pool capacity must raise, never truncate silently (the reference
+    itself would overflow its call stack on such a scene)."""
+    data = _white_room(rtm, 0.99995, w=8, h=8, s=1)
+    data.object[1].m_material.color = rtm.vec3(0.99995, 0.99995, 0.99995)  # the lamp no longer ends paths
+    with pytest.raises(rtm.RtmError) as e:
+        _gpu_image(rtm, data, "repaired", -1, 1, want=("f64",))
+    assert e.value.status == -8 and "deeper" in str(e.value)
+    with pytest.raises(rtm.RtmError):
+        _gpu_image(rtm, data, "repaired", 5000, 1, want=("f64",))
+
+
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
