@@ -71,6 +71,12 @@ int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, dou
     RTM_GUARD(rtm::math_probe(op, a, b, n, out))
 }
 
+/* diagnostic hook, not part of the documented ABI: isolated nearest-hit / shading loops */
+int rtm_debug_component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
+                              double* cycles_per_rep) {
+    RTM_GUARD(rtm::component_bench(which, sp, n, reps, blocks, lds_pad, cycles_per_rep))
+}
+
 int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,
                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
     RTM_GUARD(rtm::scene_load_json(path, literal_loader, settings, spheres, capacity, n_spheres))

@@ -35,6 +35,88 @@ __device__ __forceinline__ double magnitude(D3 a) {
 // src/Ray.h:70-72: three true divisions
 __device__ __forceinline__ D3 normalize(D3 a) { return a / magnitude(a); }
 
+// ---- selects ----
+// gfx950 issues back-to-back v_cndmask_b32_e32 (the VCC form hipcc prefers for a?b:c on doubles)
+// at ~11-13 cycles each (profiles/ubench/valu_rate.hip; an isolated one, or the e64 form, costs ~3).
+// A per-lane all-ones/zero mask made once per condition and v_bfi_b32 per dword is full rate.
+// The empty asm keeps LLVM from folding the bit-select back into a select.
+struct LaneMask {
+    uint32_t m;
+};
+__device__ __forceinline__ LaneMask lane_mask(bool c) {
+    uint32_t m = c ? 0xFFFFFFFFu : 0u;
+    asm("" : "+v"(m));
+    return LaneMask{m};
+}
+__device__ __forceinline__ uint32_t sel_u32(LaneMask k, uint32_t a, uint32_t b) {
+    return (a & k.m) | (b & ~k.m);  // v_bfi_b32
+}
+__device__ __forceinline__ int sel_i32(LaneMask k, int a, int b) {
+    return (int)sel_u32(k, (uint32_t)a, (uint32_t)b);
+}
+__device__ __forceinline__ double sel_f64(LaneMask k, double a, double b) {  // k ? a : b, bit-exact
+    const uint32_t hi = sel_u32(k, (uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b));
+    const uint32_t lo = sel_u32(k, (uint32_t)__double2loint(a), (uint32_t)__double2loint(b));
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ D3 sel_d3(LaneMask k, D3 a, D3 b) {
+    return D3{sel_f64(k, a.x, b.x), sel_f64(k, a.y, b.y), sel_f64(k, a.z, b.z)};
+}
+// x * -1.0 for the lanes of k, x elsewhere: IEEE multiplication by -1 is a sign-bit flip
+__device__ __forceinline__ double negate_where(LaneMask k, double x) {
+    return __hiloint2double(__double2hiint(x) ^ (int)(k.m & 0x80000000u), __double2loint(x));
+}
+
+// ---- sin and cos of r in [0, 2^30) without branches ----
+// The same operation sequence as the small-argument path of ROCm's ocml sincos (three-part pi/2
+// Cody-Waite reduction with FMA, then the (hi, lo) sin/cos kernels), written out so that the
+// shading block stays one basic block (ocml's entry point branches to a Payne-Hanek path the
+// renderer's r1 = 2*pi*u can never take).  Bit-identical to ::sincos on that range
+// (tests/test_parity_gpu.py::test_sincos_small_matches_ocml, all 2^23 possible r1).
+__device__ __forceinline__ void sincos_small(const double x, double& sn, double& cs) {
+    // trigredsmall
+    const double dn = __builtin_rint(x * 0x1.45f306dc9c883p-1);
+    const double xt = __builtin_fma(dn, -0x1.921fb54442d18p+0, x);
+    const double yt = __builtin_fma(dn, -0x1.1a62633145c00p-54, xt);
+    const double ph = dn * 0x1.1a62633145c00p-54;
+    const double pt = __builtin_fma(dn, 0x1.1a62633145c00p-54, -ph);
+    const double th = xt - ph;
+    const double tt = (xt - th) - ph;
+    const double c = ((th - yt) + tt) - pt;
+    const double d = __builtin_fma(dn, -0x1.b839a252049c0p-104, c);
+    const double hi = yt + d;
+    const double lo = d - (hi - yt);
+    const int q = (int)dn;
+    // sincosred2(hi, lo)
+    const double t = hi * hi;
+    const double h = t * 0.5;
+    const double c1 = 1.0 - h;
+    const double c3 = (1.0 - c1) - h;
+    const double t2 = t * t;
+    double p = __builtin_fma(t, -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29);
+    p = __builtin_fma(t, p, -0x1.27e4fa17f65f6p-22);
+    p = __builtin_fma(t, p, 0x1.a01a019f4ec90p-16);
+    p = __builtin_fma(t, p, -0x1.6c16c16c16967p-10);
+    p = __builtin_fma(t, p, 0x1.5555555555555p-5);
+    const double nlo = -lo;
+    const double cq = __builtin_fma(t2, p, __builtin_fma(hi, nlo, c3));
+    const double cosv = c1 + cq;
+    double s = __builtin_fma(t, 0x1.5e0b2f9a43bb8p-33, -0x1.ae600b42fdfa7p-26);
+    s = __builtin_fma(t, s, 0x1.71de3796cde01p-19);
+    s = __builtin_fma(t, s, -0x1.a01a019e83e5cp-13);
+    s = __builtin_fma(t, s, 0x1.1111111110bb3p-7);
+    const double v = hi * -t;
+    const double w = __builtin_fma(t, __builtin_fma(v, s, lo * 0.5), nlo);
+    const double sinv = hi - __builtin_fma(v, -0x1.5555555555555p-3, w);
+    // quadrant: sin <- (q odd ? cos : sin), cos <- (q odd ? -sin : cos); both negated for q & 2
+    const bool odd = (q & 1) != 0;
+    const int flip = (q & 2) ? (int)0x80000000 : 0;
+    const double so = odd ? cosv : sinv;
+    const double co = odd ? -sinv : cosv;
+    sn = __hiloint2double(__double2hiint(so) ^ flip, __double2loint(so));
+    cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
+}
+
 // ---- build-defined counter RNG; must agree with rtm_rng_u01 on the host ----
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16;

@@ -29,6 +29,8 @@ int intersect_batch(const rtm_sphere* sp, const double* org, const double* dir, 
 int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample, uint32_t n_draws,
               double* out);
 double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t index);
+int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
+                    double* cycles_per_rep);
 int math_probe(int op, const double* a, const double* b, size_t n, double* out);
 
 // host side (rtm_scene.cpp, rtm_image.cpp)

@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -56,6 +57,7 @@ struct RenderParams {
     unsigned char* __restrict__ pool;       // pool_slots x kPoolLevels records
     unsigned* __restrict__ pool_next;       // bump allocator
     unsigned pool_slots;
+    unsigned debug_flags;  // diagnostics only (RTM_DEBUG_FLAGS): bit 0 = skip the fold (WRONG image)
 };
 
 constexpr int kPoolLevels = 960;  // records per pool slot beyond the LDS levels
@@ -97,6 +99,10 @@ struct RecordStack {
     }
     static constexpr int kCapacity = LDS_D + kPoolLevels;
 };
+
+// LDS copy of the scene tables: n geometry rows (4 doubles) + n+1 material rows (8 doubles, the last
+// one is the identity row), rounded up to 16 bytes
+__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 4 + ((size_t)n + 1) * 8) * sizeof(double); }
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
 __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
@@ -142,17 +148,17 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //   UNROLL  spheres whose geometry is fetched together (wave-uniform loads)
 //   RecT    hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged in LDS per lane
 // Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat n*8 doubles][records].
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D>
-__global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) {
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1>
+__global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
     double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
-    RecT* rec = reinterpret_cast<RecT*>(lmat + (LDS_TAB ? P.scene.n * 8 : 0));
+    RecT* rec = reinterpret_cast<RecT*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
     if constexpr (LDS_TAB) {
         const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
         for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
-        for (int i = lane; i < P.scene.n * 8; i += 64) lmat[i] = P.scene.mat[i];
+        for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
         __syncthreads();  // one wave per block: orders the LDS writes before the reads
     }
     using Scene = typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type;
@@ -194,11 +200,16 @@ __global__ __launch_bounds__(64) void render_tiles_kernel(const RenderParams P) 
             depth = 0;
         }
         if (!cont) {
-            const D3 L = path_fold(sc, term, depth, pop);
+            // all ending lanes within the LDS levels (always, when max_bounces < 16): blocked fold
+            const bool deep = depth > LDS_D;
+            const D3 L = (P.debug_flags & 1u) ? term
+                         : (__builtin_amdgcn_ballot_w64(deep) == 0)
+                             ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
+                             : path_fold(sc, term, depth, pop);
             // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
             // power-of-two divisors are applied as multiplications.
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
-            acc = acc + d3(clamp01(cal.x), clamp01(cal.y), clamp01(cal.z));  // :241-242
+            acc = acc + clamp01_d3(cal);  // :241-242
             ++n;
             if (++s_in_sub == P.S) {
                 s_in_sub = 0;
@@ -307,16 +318,19 @@ __global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderPar
         // ---- shade / bookkeeping, per lane ----
         if (ns < P.total_samples) {
             D3 term;
-            bool cont = path_shade<M>(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
+            bool cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
             if (cont && stack.overflow) {
                 cont = false;
                 term = d3(0, 0, 0);
                 depth = 0;
             }
             if (!cont) {
-                const D3 L = path_fold(sc, term, depth, pop);
+                const bool deep = depth > LDS_D;
+                const D3 L = (__builtin_amdgcn_ballot_w64(deep) == 0)
+                                 ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
+                                 : path_fold(sc, term, depth, pop);
                 const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
-                acc = acc + d3(clamp01(cal.x), clamp01(cal.y), clamp01(cal.z));
+                acc = acc + clamp01_d3(cal);
                 ++ns;
                 if (++s_in_sub == P.S) {
                     s_in_sub = 0;
@@ -426,6 +440,74 @@ __global__ void rng_batch_kernel(uint64_t seed_mult, uint32_t pixel0, uint32_t n
     for (uint32_t k = 0; k < n_draws; ++k) out[(size_t)p * n_draws + k] = rng_next(s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Component micro-benchmarks (profiles/component_bench.py): the nearest-hit loop and the shading
+// block in isolation, timed with s_memtime, same policies as the render kernel.
+template <class M, int UNROLL>
+__global__ __launch_bounds__(64) void nearest_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
+                                                           unsigned long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    SceneGlobal sc;
+    sc.v = scene;
+    const int lane = threadIdx.x;
+    D3 dir = normalize(d3(-0.8 + 0.025 * (lane & 7) + 1e-3 * blockIdx.x, -0.5 + 0.12 * (lane >> 3), 1.0));
+    D3 org = org0;
+    double acc = 0.0;
+    int ids = 0;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int r = 0; r < reps; ++r) {
+        double dis;
+        const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+        acc += dis;
+        ids += id;
+        org.x += 1e-7 * (id + 2);  // the next cast depends on this one, like a path
+    }
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    out[(size_t)blockIdx.x * 64 + lane] = acc + ids;
+    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+    if (lds_raw[0] == 77 && reps < 0) out[0] = 1;  // keeps the dynamic LDS allocation alive
+}
+
+template <class M>
+__global__ __launch_bounds__(64) void shade_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
+                                                         unsigned long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    SceneGlobal sc;
+    sc.v = scene;
+    const int lane = threadIdx.x;
+    D3 dir = normalize(d3(-0.8 + 0.025 * (lane & 7) + 1e-3 * blockIdx.x, -0.5 + 0.12 * (lane >> 3), 1.0));
+    D3 org = org0;
+    RngStream rng = rng_open(rng_pixel_key(12345, blockIdx.x * 64 + lane), 0);
+    PathCounters pc = {0, 0, 0};
+    double acc = 0.0;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int r = 0; r < reps; ++r) {
+        int depth = 0;
+        D3 term;
+        // hit sphere 1 (a wall, kd 0.9) at a fixed distance: ~90 % of the lanes continue
+        bool cont;
+        if constexpr (std::is_same<M, MathFast>::value)
+            cont = path_shade_spec(sc, 1, 9.5 + 1e-3 * lane, RTM_MODE_REPAIRED, -1, org, dir, depth, rng, term, pc,
+                                   [](int, int) {});
+        else
+            cont = path_shade<M>(sc, 1, 9.5 + 1e-3 * lane, RTM_MODE_REPAIRED, -1, org, dir, depth, rng, term, pc,
+                                 [](int, int) {});
+        if (!cont) {
+            acc += term.x;
+            org = org0;
+        }
+        org.x *= 0.5;
+        org.y *= 0.5;
+        org.z = org.z * 0.5 - 5.0;
+    }
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    out[(size_t)blockIdx.x * 64 + lane] = acc + dir.x + org.y + pc.draws;
+    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+    if (lds_raw[0] == 77 && reps < 0) out[0] = 1;
+}
+
 // Device primitives exposed for parity tests of the building blocks (tests/test_device_math.py).
 __global__ void math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                   size_t n, double* __restrict__ out) {
@@ -443,6 +525,10 @@ __global__ void math_probe_kernel(int op, const double* __restrict__ a, const do
         case 6: sincos(x, &s, &c); r = c; break;
         case 7: r = x * y + 1.0; break;  // must NOT be contracted to an fma
         case 8: r = MathFast::sqrt64(x); break;
+        case 12: sincos_small(x, s, c); r = s; break;
+        case 13: sincos_small(x, s, c); r = c; break;
+        case 14: { MathSpec m; r = m.sqrt64(x); if (m.bad) r = ::sqrt(x); } break;
+        case 15: { MathSpec m; r = m.div3(d3(x, 1.0, -x), y).x; if (m.bad) r = x / y; } break;
         case 9: r = MathFast::div3(d3(x, x * 0.5, -x), y).x; break;
         case 10: r = MathFast::div3(d3(1.0, x, 0.0), y).y; break;
         case 11: r = MathFast::div3(d3(y, -0.0, x), y).z; break;
@@ -488,7 +574,8 @@ static H3 normalize(H3 a) {
 static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& geom,
                           std::vector<double>& mat) {
     geom.resize(n * 4);
-    mat.resize(n * 8);
+    mat.assign((n + 1) * 8, 0.0);
+    mat[n * 8 + 0] = mat[n * 8 + 1] = mat[n * 8 + 2] = 1.0;  // identity row for path_fold_blocked
     for (size_t i = 0; i < n; ++i) {
         const float r2 = sp[i].radius * sp[i].radius;  // float product, src/SettingData.cpp:200
         geom[i * 4 + 0] = sp[i].center[0];
@@ -512,6 +599,10 @@ static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& g
 __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n,
                                      double* __restrict__ geom, double* __restrict__ mat) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) {  // identity row for path_fold_blocked
+        for (int k = 0; k < 8; ++k) mat[n * 8 + k] = (k < 3) ? 1.0 : 0.0;
+        return;
+    }
     if (i >= n) return;
     const float r2 = sp[i].radius * sp[i].radius;
     geom[i * 4 + 0] = sp[i].center[0];
@@ -541,19 +632,19 @@ struct DeviceScene {
         stream = st;
         const size_t nn = n ? n : 1;
         RTM_HIP_CHECK(hipMallocAsync((void**)&geom, nn * 4 * sizeof(double), stream));
-        RTM_HIP_CHECK(hipMallocAsync((void**)&mat, nn * 8 * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMallocAsync((void**)&mat, (n + 1) * 8 * sizeof(double), stream));
         RTM_HIP_CHECK(hipMallocAsync((void**)&counters, 4 * sizeof(unsigned long long), stream));
         RTM_HIP_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), stream));
-        if (n == 0) return RTM_OK;
         if (on_device) {
-            flatten_scene_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(sp, n, geom, mat);
+            flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, stream>>>(sp, n, geom, mat);
             RTM_HIP_CHECK(hipGetLastError());
         } else {
             std::vector<double> hg, hm;
             flatten_scene(sp, n, hg, hm);
             // pageable source: the copy is staged before the call returns
-            RTM_HIP_CHECK(hipMemcpyAsync(geom, hg.data(), hg.size() * sizeof(double),
-                                         hipMemcpyHostToDevice, stream));
+            if (n)
+                RTM_HIP_CHECK(hipMemcpyAsync(geom, hg.data(), hg.size() * sizeof(double),
+                                             hipMemcpyHostToDevice, stream));
             RTM_HIP_CHECK(hipMemcpyAsync(mat, hm.data(), hm.size() * sizeof(double),
                                          hipMemcpyHostToDevice, stream));
             RTM_HIP_CHECK(hipStreamSynchronize(stream));
@@ -604,8 +695,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 }
 
 // variant 0 = auto (the fastest parity-validated kernel for the scene size)
-static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-u4",
-                                      "fast-math-global-scene-u4", "fast-math-lds-scene-tiles"};
+static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8",
+                                      "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
+                                      "fast-math-lds-tables-chunk8-occ5", "fast-math-lds-tables-chunk8-occ6",
+                                      "fast-math-lds-tables-chunk8-occ8"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
               kVariantSceneTiled = 4;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
@@ -647,6 +740,7 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.by = D3{cam_y.x * fovy, cam_y.y * fovy, cam_y.z * fovy};  // l_camY * fovy, :230
     P.cz = D3{direction.x, direction.y, direction.z};
     P.seed_mult = seed_multiplier(opt->seed);
+    if (const char* e = std::getenv("RTM_DEBUG_FLAGS")) P.debug_flags = (unsigned)std::strtoul(e, nullptr, 0);
 }
 
 // LDS record levels: 16 when the cap guarantees depth < 16; otherwise 64 (u8) / 32 (u32) levels in
@@ -655,14 +749,23 @@ template <typename RecT>
 constexpr int deep_lds_levels() { return sizeof(RecT) == 1 ? 64 : 32; }
 static bool needs_pool(const RenderParams& P) { return !(P.max_bounces >= 0 && P.max_bounces < 16); }
 
-template <class M, bool LDS_TAB, int UNROLL, typename RecT>
+// diagnostic knob (profiles/occupancy_sweep.sh): extra dynamic LDS per workgroup caps the waves/CU
+static size_t debug_lds_pad() {
+    static const size_t pad = [] {
+        const char* e = std::getenv("RTM_DEBUG_LDS_PAD");
+        return e ? (size_t)std::strtoul(e, nullptr, 10) : (size_t)0;
+    }();
+    return pad;
+}
+
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    const size_t tab = LDS_TAB ? (size_t)P.scene.n * 12 * sizeof(double) : 0;
+    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + debug_lds_pad();
     constexpr int DEEP = deep_lds_levels<RecT>();
     if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
 template <typename RecT>
@@ -692,10 +795,16 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
-        launch_render_depth<MathFast, true, 4, uint8_t>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4>(P, grid, stream);
+    } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
+        launch_render_depth<MathFast, true, 8, uint8_t, 5>(P, grid, stream);
+    } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
+        launch_render_depth<MathFast, true, 8, uint8_t, 6>(P, grid, stream);
+    } else if (variant == 7 && n <= kLdsTableMaxSpheres) {
+        launch_render_depth<MathFast, true, 8, uint8_t, 8>(P, grid, stream);
     } else {
-        if (n <= 256) launch_render_depth<MathFast, false, 4, uint8_t>(P, grid, stream);
-        else launch_render_depth<MathFast, false, 4, uint32_t>(P, grid, stream);
+        if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
+        else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
     }
 }
 
@@ -936,6 +1045,42 @@ int math_probe(int op, const double* a, const double* b, size_t n, double* out) 
     (void)hipFree(da);
     (void)hipFree(dout);
     if (db) (void)hipFree(db);
+    return RTM_OK;
+}
+
+// which: 0 nearest ref/1, 1 nearest fast/1 (sphere_test loop), 2 nearest fast/4 (batched), 3 nearest
+// fast/2, 10 shade ref, 11 shade fast.  Returns average cycles per repetition per wave.
+int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
+                    double* cycles_per_rep) {
+    DeviceScene ds;
+    int rc = ds.upload(sp, n, 0, nullptr);
+    if (rc != RTM_OK) return rc;
+    double* out;
+    unsigned long long* cyc;
+    RTM_HIP_CHECK(hipMalloc((void**)&out, (size_t)blocks * 64 * 8));
+    RTM_HIP_CHECK(hipMalloc((void**)&cyc, (size_t)blocks * 8));
+    const SceneView sv{(const double4*)ds.geom, ds.mat, (int)n};
+    const D3 org0 = D3{0.0, 0.0, -10.0};
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass ? reps : 4;
+        switch (which) {
+            case 0: nearest_bench_kernel<MathRef, 1><<<blocks, 64, lds_pad>>>(sv, org0, r, out, cyc); break;
+            case 1: nearest_bench_kernel<MathFast, 1><<<blocks, 64, lds_pad>>>(sv, org0, r, out, cyc); break;
+            case 2: nearest_bench_kernel<MathFast, 8><<<blocks, 64, lds_pad>>>(sv, org0, r, out, cyc); break;
+            case 10: shade_bench_kernel<MathRef><<<blocks, 64, lds_pad>>>(sv, org0, r, out, cyc); break;
+            case 11: shade_bench_kernel<MathFast><<<blocks, 64, lds_pad>>>(sv, org0, r, out, cyc); break;
+            default: return RTM_ERR_INVALID_ARGUMENT;
+        }
+        RTM_HIP_CHECK(hipGetLastError());
+        RTM_HIP_CHECK(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> h(blocks);
+    RTM_HIP_CHECK(hipMemcpy(h.data(), cyc, (size_t)blocks * 8, hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (auto v : h) sum += (double)v;
+    *cycles_per_rep = sum / blocks / reps;
+    (void)hipFree(out);
+    (void)hipFree(cyc);
     return RTM_OK;
 }
 

@@ -5,6 +5,7 @@
 // Citations are file:line in the reference checkout.
 #pragma once
 #include <cfloat>
+#include <type_traits>
 
 #include "../../include/rtm.h"
 #include "rtm_device.h"
@@ -19,6 +20,11 @@ namespace rtm {
 struct MathRef {
     static __device__ __forceinline__ double sqrt64(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ D3 div3(D3 a, double y) { return a / y; }
+    template <int K>
+    static __device__ __forceinline__ void sqrt64_batch(const double (&x)[K], double (&out)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
+    }
 };
 
 // MathFast: the same instruction sequences with the range-scaling steps hoisted into one
@@ -52,6 +58,40 @@ struct MathFast {
         const double d1 = __builtin_fma(-s2, s2, x);
         return __builtin_fma(d1, h1, s2);
     }
+    static __device__ __forceinline__ bool sqrt_fast_ok(double x) {
+        const unsigned h = (unsigned)__double2hiint(x);
+        return (h - 0x10000000u < 0x6FF00000u) || (h > 0x80000000u);
+    }
+    // K independent square roots behind ONE wave-uniform guard (one branch per batch, and K
+    // independent dependency chains for the scheduler to interleave)
+    template <int K>
+    static __device__ __forceinline__ void sqrt64_batch(const double (&x)[K], double (&out)[K]) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ok = ok && sqrt_fast_ok(x[k]);
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
+            return;
+        }
+        double y[K], s0[K], h0[K], r0[K], s1[K], h1[K], d0[K], s2[K], d1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = __builtin_amdgcn_rsq(x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { s0[k] = x[k] * y[k]; h0[k] = 0.5 * y[k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) r0[k] = __builtin_fma(-h0[k], s0[k], 0.5);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { s1[k] = __builtin_fma(s0[k], r0[k], s0[k]); h1[k] = __builtin_fma(h0[k], r0[k], h0[k]); }
+#pragma unroll
+        for (int k = 0; k < K; ++k) d0[k] = __builtin_fma(-s1[k], s1[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) s2[k] = __builtin_fma(d0[k], h1[k], s1[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) d1[k] = __builtin_fma(-s2[k], s2[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = __builtin_fma(d1[k], h1[k], s2[k]);
+    }
     static __device__ __forceinline__ D3 div3(D3 a, double y) {
         const bool ok = moderate(y) && moderate(a.x) && moderate(a.y) && moderate(a.z);
         if (__builtin_amdgcn_ballot_w64(!ok) != 0) return a / y;
@@ -69,10 +109,63 @@ struct MathFast {
     }
 };
 
+// MathSpec: speculate.  Every sqrt / division runs MathFast's unscaled sequence unconditionally and
+// records, per lane, whether an operand was outside the range in which that sequence is the
+// compiler's own (bit-identical) expansion.  The caller checks `bad` once per block with a ballot
+// and re-runs the block with MathRef if any lane tripped it — one branch per block instead of one
+// per operation, and one long basic block for the scheduler.
+struct MathSpec {
+    bool bad = false;
+    __device__ __forceinline__ double sqrt64(double x) {
+        bad = bad || !MathFast::sqrt_fast_ok(x);
+        const double y = __builtin_amdgcn_rsq(x);
+        const double s0 = x * y, h0 = 0.5 * y;
+        const double r0 = __builtin_fma(-h0, s0, 0.5);
+        const double s1 = __builtin_fma(s0, r0, s0), h1 = __builtin_fma(h0, r0, h0);
+        const double d0 = __builtin_fma(-s1, s1, x);
+        const double s2 = __builtin_fma(d0, h1, s1);
+        const double d1 = __builtin_fma(-s2, s2, x);
+        return __builtin_fma(d1, h1, s2);
+    }
+    __device__ __forceinline__ D3 div3(D3 a, double y) {
+        bad = bad || !(MathFast::moderate(y) && MathFast::moderate(a.x) && MathFast::moderate(a.y) &&
+                       MathFast::moderate(a.z));
+        double r = __builtin_amdgcn_rcp(y);
+        double e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        auto one = [&](double x) {
+            const double q = x * r;
+            const double rem = __builtin_fma(-y, q, x);
+            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+        };
+        return D3{one(a.x), one(a.y), one(a.z)};
+    }
+    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos_small(x, sn, cs); }
+};
+// instance adaptors so that path_shade can take any policy as an object
+struct MathRefI {
+    static constexpr bool bad = false;
+    __device__ __forceinline__ double sqrt64(double x) { return MathRef::sqrt64(x); }
+    __device__ __forceinline__ D3 div3(D3 a, double y) { return MathRef::div3(a, y); }
+    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
+};
+struct MathFastI {
+    static constexpr bool bad = false;
+    __device__ __forceinline__ double sqrt64(double x) { return MathFast::sqrt64(x); }
+    __device__ __forceinline__ D3 div3(D3 a, double y) { return MathFast::div3(a, y); }
+    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
+};
+
 // src/Ray.h:67-72 through a policy
 template <class M>
 __device__ __forceinline__ D3 normalize_m(D3 a) {
     return M::div3(a, magnitude(a));
+}
+template <class MI>
+__device__ __forceinline__ D3 normalize_i(MI& m, D3 a) {
+    return m.div3(a, magnitude(a));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -85,12 +178,26 @@ struct SceneView {
     int n;
 };
 
+// Wave-uniform geometry fetch.  The tables are never written while a render kernel runs, but the
+// kernel also stores through unrelated pointers (pixels, pooled records), which makes hipcc fall
+// back to per-lane vector loads; reading through the constant address space states the invariance
+// and brings back scalar loads (s_load_dwordx8 into SGPRs, one per sphere per wave).
+__device__ __forceinline__ double4 load_geom_uniform(const double4* geom, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+    ConstF64Ptr p = (ConstF64Ptr)(unsigned long long)(geom + i);
+    return double4{p[0], p[1], p[2], p[3]};
+#else
+    return geom[i];
+#endif
+}
+
 // Everything from global memory (uniform geometry loads become scalar loads; per-lane material and
 // centre look-ups are vector gathers served by L1/L2).  Works for any n.
 struct SceneGlobal {
     SceneView v;
     __device__ __forceinline__ int n() const { return v.n; }
-    __device__ __forceinline__ double4 geom_uniform(int i) const { return v.geom[i]; }
+    __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
         const double4 g = v.geom[id];
         return D3{g.x, g.y, g.z};
@@ -113,7 +220,7 @@ struct SceneLds {
     const double* lgeom;  // LDS, 4 doubles per sphere
     const double* lmat;   // LDS, 8 doubles per sphere
     __device__ __forceinline__ int n() const { return v.n; }
-    __device__ __forceinline__ double4 geom_uniform(int i) const { return v.geom[i]; }
+    __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
         const double* g = lgeom + id * 4;
         return D3{g[0], g[1], g[2]};
@@ -169,8 +276,35 @@ __device__ __forceinline__ void sphere_update(const double4 g, const D3 org, con
     hit_object = accept ? i : hit_object;
 }
 
+// K consecutive spheres starting at i0 as ONE basic block: K independent Intersect evaluations
+// (independent dependency chains the scheduler interleaves), their square roots behind a single
+// wave-uniform guard, then the K acceptance updates in index order (strict <: the lowest index still
+// wins ties).  Select-only form, see sphere_update for the equivalence with the statement order.
+// profiles/ubench/nearest_variants.hip: 36 % fewer cycles per cast than the per-sphere loop.
+template <class M, int K, class Scene>
+__device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
+                                             double& dis, int& hit_object) {
+    double b[K], D4[K], sq[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double4 g = sc.geom_uniform(i0 + k);
+        const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
+        b[k] = dot(p_o, dir);                                      // :199
+        D4[k] = b[k] * b[k] - dot(p_o, p_o) + g.w;                 // :200
+    }
+    M::template sqrt64_batch<K>(D4, sq);                           // :205 (D4 < 0 gives NaN: no hit)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
+        const double t = (t1 > 0.001) ? t1 : t2;
+        const bool accept = (t < dis) && !(t < (double)1e-5f);
+        dis = accept ? t : dis;
+        hit_object = accept ? i0 + k : hit_object;
+    }
+}
+
 // src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
-// UNROLL > 1 fetches the geometry of UNROLL spheres (wave-uniform loads) before testing them.
+// UNROLL == 1: the literal loop.  UNROLL > 1: batches of UNROLL spheres (sphere_batch).
 template <class M, int UNROLL, class Scene>
 __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
     int hit_object = -1;
@@ -186,13 +320,18 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
             }
         }
     } else {
-        for (int i0 = 0; i0 < n; i0 += UNROLL) {
-            double4 g[UNROLL];
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) g[k] = sc.geom_uniform(i0 + k < n ? i0 + k : n - 1);
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k)
-                if (i0 + k < n) sphere_update<M>(g[k], org, dir, i0 + k, dis, hit_object);  // uniform
+        static_assert(UNROLL == 8, "chunked form is written for chunks of 8 plus an exact tail");
+        int i0 = 0;
+        for (; i0 + 8 <= n; i0 += 8) sphere_chunk<M, 8>(sc, i0, org, dir, dis, hit_object);
+        switch (n - i0) {  // wave-uniform: exactly one tail chunk, sized to the remainder
+            case 1: sphere_chunk<M, 1>(sc, i0, org, dir, dis, hit_object); break;
+            case 2: sphere_chunk<M, 2>(sc, i0, org, dir, dis, hit_object); break;
+            case 3: sphere_chunk<M, 3>(sc, i0, org, dir, dis, hit_object); break;
+            case 4: sphere_chunk<M, 4>(sc, i0, org, dir, dis, hit_object); break;
+            case 5: sphere_chunk<M, 5>(sc, i0, org, dir, dis, hit_object); break;
+            case 6: sphere_chunk<M, 6>(sc, i0, org, dir, dis, hit_object); break;
+            case 7: sphere_chunk<M, 7>(sc, i0, org, dir, dis, hit_object); break;
+            default: break;
         }
     }
     return hit_object;
@@ -205,11 +344,12 @@ struct PathCounters {
 // The part of one PathTracing invocation (src/Renderer.cpp:57-117) after the nearest-hit loop:
 // `id`/`dis` are that loop's result.  Returns true when the path continues (org/dir/depth updated,
 // hit id pushed through `push`); false when it ended with `term` = the value the deepest invocation
-// returned.
-template <class M, class Scene, typename PushFn>
-__device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const double dis, const int mode,
-                                           const int max_bounces, D3& org, D3& dir, int& depth,
-                                           RngStream& rng, D3& term, PathCounters& pc, PushFn push) {
+// returned.  `m` is a math policy object (MathRefI, MathFastI or MathSpec).
+template <class MI, class Scene, typename PushFn>
+__device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const int id, const double dis,
+                                                const int mode, const int max_bounces, D3& org, D3& dir,
+                                                int& depth, RngStream& rng, D3& term, PathCounters& pc,
+                                                PushFn push) {
     pc.casts++;
     if (id < 0) {  // :116
         term = d3(0, 0, 0);
@@ -227,28 +367,67 @@ __device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const 
     }
     const D3 hit_point = dir * dis + org;  // :79
     // D2: in literal mode the caller's normal stays (0,0,0); repaired: src/SettingData.cpp:214-215
-    const D3 normal = (mode == RTM_MODE_LITERAL) ? d3(0, 0, 0)
-                                                 : normalize_m<M>(hit_point - sc.center(id));
-    const D3 w = dot(normal, dir) < 0.0 ? normal : normal * -1.0;  // :82-83
+    const D3 normal =
+        (mode == RTM_MODE_LITERAL) ? d3(0, 0, 0) : normalize_i(m, hit_point - sc.center(id));
+    // :82-83  w = Dot(n, d) < 0 ? n : n * -1.0  (multiplying by -1.0 flips the sign bit, exactly)
+    const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));
+    const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
     pc.draws += 2;
     const double r1 = 6.283185307179586 * rng_next(rng);  // :88  (2*PI folded)
     const double r2 = rng_next(rng);                      // :89
-    const double r2s = M::sqrt64(r2);                     // :90
+    const double r2s = m.sqrt64(r2);                      // :90
     // :96-101 — one Normalize on the selected cross product (same values as the two-armed if)
     const bool use_y = fabs(w.x) > (double)FLT_MIN;
-    const D3 cy = cross(d3(0, 1, 0), w), cx = cross(d3(1, 0, 0), w);
-    const D3 u = normalize_m<M>(use_y ? cy : cx);
+    D3 c = cross(d3(0, 1, 0), w);
+    if (__builtin_amdgcn_ballot_w64(!use_y) != 0) {  // some lane has |w.x| <= FLT_MIN (e.g. literal mode)
+        const D3 cx = cross(d3(1, 0, 0), w);
+        c = d3(use_y ? c.x : cx.x, use_y ? c.y : cx.y, use_y ? c.z : cx.z);
+    }
+    const D3 u = normalize_i(m, c);
     const D3 v = cross(w, u);  // :102
     double sn, cs;
-    sincos(r1, &sn, &cs);
-    const D3 nd =
-        normalize_m<M>((u * cs) * r2s + (v * sn) * r2s + w * M::sqrt64(1.0 - r2));  // :103-107
+    m.sincos_r1(r1, sn, cs);
+    const D3 nd = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
     push(depth, id);
     depth++;
     pc.bounces++;
     org = hit_point;
     dir = nd;
     return true;
+}
+
+// Static-policy form (M = MathRef or MathFast).
+template <class M, class Scene, typename PushFn>
+__device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const double dis, const int mode,
+                                           const int max_bounces, D3& org, D3& dir, int& depth,
+                                           RngStream& rng, D3& term, PathCounters& pc, PushFn push) {
+    typename std::conditional<std::is_same<M, MathRef>::value, MathRefI, MathFastI>::type m;
+    return path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+}
+
+// Speculative form: the whole shading block with MathSpec (one basic block), then ONE check; if any
+// lane's operand was outside MathSpec's exact range the block is re-run with the compiler's math
+// from the saved inputs (push is idempotent, counters and RNG are restored).
+template <class Scene, typename PushFn>
+__device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, const double dis, const int mode,
+                                                const int max_bounces, D3& org, D3& dir, int& depth,
+                                                RngStream& rng, D3& term, PathCounters& pc, PushFn push) {
+    const D3 org0 = org, dir0 = dir;
+    const int depth0 = depth;
+    const RngStream rng0 = rng;
+    const PathCounters pc0 = pc;
+    MathSpec m;
+    bool cont = path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+    if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
+        org = org0;
+        dir = dir0;
+        depth = depth0;
+        rng = rng0;
+        pc = pc0;
+        MathRefI r;
+        cont = path_shade_with(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+    }
+    return cont;
 }
 
 // One PathTracing invocation: nearest-hit loop + shading.
@@ -258,7 +437,10 @@ __device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const
                                           PathCounters& pc, PushFn push) {
     double dis;
     const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
-    return path_shade<M>(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+    if constexpr (std::is_same<M, MathFast>::value)
+        return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+    else
+        return path_shade<M>(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
 }
 
 // Fold the recursion back to front: L = colorKD * L_next + emission (src/Renderer.cpp:109).
@@ -272,10 +454,48 @@ __device__ __forceinline__ D3 path_fold(const Scene& sc, const D3 term, const in
     return L;
 }
 
+// The same fold, four levels per trip.  The literal loop is a chain of dependent LDS round trips
+// (record -> material row -> 6 flops, per level) and cost 17 % of the frame; here the four records
+// and then the four material rows of a trip are fetched together, and only the 4 x (mul, add) steps
+// remain serial.  Levels a lane does not have use the identity row the material table carries at
+// index n (colorKD = 1, emission = +0): L*1 + 0 is L (only a -0 would become +0, which no later
+// operation can tell apart).  `pop_lds(d)` must be valid for 0 <= d < depth.
+template <class Scene, typename PopFn>
+__device__ __forceinline__ D3 path_fold_blocked(const Scene& sc, const D3 term, const int depth, PopFn pop_lds) {
+    D3 L = term;
+    const int identity = sc.n();
+    int d = depth - 1;
+    while (__builtin_amdgcn_ballot_w64(d >= 0) != 0) {
+        int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int raw = pop_lds(d - k > 0 ? d - k : 0);
+            id[k] = (d - k >= 0) ? raw : identity;
+        }
+        D3 c[4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = sc.color_kd(id[k]);
+            e[k] = sc.emission(id[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
+        d -= 4;
+    }
+    return L;
+}
+
 // src/Renderer.cpp:43-49: std::min<double>(std::max<double>(v, 0), 1.0f)
 __device__ __forceinline__ double clamp01(double v) {
     const double lo = (v < 0.0) ? 0.0 : v;
     return (1.0 < lo) ? 1.0 : lo;
+}
+// clampColor on a vec3.  The clamp is the identity unless a channel is < 0 or > 1 (NaN passes
+// through both comparisons unchanged), so the selects run only when some lane needs them.
+__device__ __forceinline__ D3 clamp01_d3(D3 c) {
+    const bool out = (c.x < 0.0) || (1.0 < c.x) || (c.y < 0.0) || (1.0 < c.y) || (c.z < 0.0) || (1.0 < c.z);
+    if (__builtin_amdgcn_ballot_w64(out) == 0) return c;
+    return D3{clamp01(c.x), clamp01(c.y), clamp01(c.z)};
 }
 
 }  // namespace rtm

@@ -104,6 +104,39 @@ def test_fast_math_is_bit_identical(rtm):
             assert same.all(), (op, xs[~same][:5], y[~same][:5], got[~same][:5], want[~same][:5])
 
 
+def test_sincos_small_matches_ocml(rtm):
+    """The branch-free sincos of the shading block is the operation sequence of ocml's small-argument
+    path: bit-identical to ::sincos for EVERY r1 = 2*pi*u the RNG can produce (u = odd * 2^-24)."""
+    for lo in range(0, 1 << 23, 1 << 21):
+        k = np.arange(lo, lo + (1 << 21), dtype=np.float64)
+        r1 = 6.283185307179586 * ((2 * k + 1) / 16777216.0)
+        assert np.array_equal(_probe(rtm, 12, r1).view(np.uint64), _probe(rtm, 5, r1).view(np.uint64))
+        assert np.array_equal(_probe(rtm, 13, r1).view(np.uint64), _probe(rtm, 6, r1).view(np.uint64))
+    x = np.concatenate([np.linspace(0, 1e6, 100001), [0.0, 1e-300, 2.0 ** 29, 1.5707963267948966, 3.141592653589793]])
+    assert np.array_equal(_probe(rtm, 12, x).view(np.uint64), _probe(rtm, 5, x).view(np.uint64))
+    assert np.array_equal(_probe(rtm, 13, x).view(np.uint64), _probe(rtm, 6, x).view(np.uint64))
+
+
+def test_speculative_math_is_bit_identical(rtm):
+    """MathSpec + its validity flag (falls back when set) == compiler math, all operand classes."""
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, n), 2.0 ** rng.uniform(-1070, -700, 4096),
+                        [0.0, -0.0, np.inf, np.nan, -1.0, 5e-324, 2.0 ** -767, 1.0]])
+    with np.errstate(invalid="ignore"):
+        want = np.sqrt(x)
+    got = _probe(rtm, 14, x)
+    assert np.array_equal(got, want, equal_nan=True)
+    yf = np.concatenate([(10.0 ** rng.uniform(-6, 6, x.size - 6)).astype(np.float32),
+                         np.array([0.0, np.inf, 1e-45, 1.0, 3.0, np.float32(1e38)], dtype=np.float32)])
+    y = yf.astype(np.float64)
+    with np.errstate(all="ignore"):
+        want = x / y
+        got = _probe(rtm, 15, x, y)
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all()
+
+
 def test_device_rng_matches_host_and_oracle(rtm, oracle):
     out = np.zeros((64, 40), dtype=np.float64)
     rtm._lib.check(rtm.lib().rtm_rng_batch(0x5EED, 1000, 64, 3, 40, out.ctypes.data), "rng_batch")
