@@ -73,17 +73,48 @@ __device__ __forceinline__ double negate_where(LaneMask k, double x) {
 // shading block stays one basic block (ocml's entry point branches to a Payne-Hanek path the
 // renderer's r1 = 2*pi*u can never take).  Bit-identical to ::sincos on that range
 // (tests/test_parity_gpu.py::test_sincos_small_matches_ocml, all 2^23 possible r1).
-__device__ __forceinline__ void sincos_small(const double x, double& sn, double& cs) {
+// Constants of sincos_small in the order the LDS copy (TrigTable) holds them.
+struct TrigConsts {
+    double two_over_pi, pio2_h, pio2_m, pio2_t;
+    double c5, c4, c3, c2, c1, c0;   // cos kernel, highest degree first
+    double s4, s3, s2, s1, s0, third;  // sin kernel, highest degree first; third = -1/6
+};
+constexpr int kTrigConstCount = 16;
+__host__ __device__ __forceinline__ constexpr TrigConsts trig_consts() {
+    return TrigConsts{0x1.45f306dc9c883p-1, 0x1.921fb54442d18p+0, 0x1.1a62633145c00p-54, 0x1.b839a252049c0p-104,
+                      -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29, -0x1.27e4fa17f65f6p-22, 0x1.a01a019f4ec90p-16,
+                      -0x1.6c16c16c16967p-10, 0x1.5555555555555p-5,
+                      0x1.5e0b2f9a43bb8p-33, -0x1.ae600b42fdfa7p-26, 0x1.71de3796cde01p-19, -0x1.a01a019e83e5cp-13,
+                      0x1.1111111110bb3p-7, -0x1.5555555555555p-3};
+}
+// K provides the constants: TrigConsts by value (immediates / registers) or a pointer-backed reader
+// (LDS copy).  hipcc hoists fp64 literals out of the render loop into VGPRs and then spills them
+// to scratch; reading them from LDS where they are used keeps them out of the register file.
+struct TrigFromRegs {
+    __device__ __forceinline__ double operator[](int i) const {
+        constexpr TrigConsts k = trig_consts();
+        const double t[kTrigConstCount] = {k.two_over_pi, k.pio2_h, k.pio2_m, k.pio2_t, k.c5, k.c4, k.c3, k.c2,
+                                           k.c1, k.c0, k.s4, k.s3, k.s2, k.s1, k.s0, k.third};
+        return t[i];
+    }
+};
+struct TrigFromLds {
+    const double* p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+template <class K>
+__device__ __forceinline__ void sincos_small_k(const K& k, const double x, double& sn, double& cs) {
     // trigredsmall
-    const double dn = __builtin_rint(x * 0x1.45f306dc9c883p-1);
-    const double xt = __builtin_fma(dn, -0x1.921fb54442d18p+0, x);
-    const double yt = __builtin_fma(dn, -0x1.1a62633145c00p-54, xt);
-    const double ph = dn * 0x1.1a62633145c00p-54;
-    const double pt = __builtin_fma(dn, 0x1.1a62633145c00p-54, -ph);
+    const double pio2_m = k[2];
+    const double dn = __builtin_rint(x * k[0]);
+    const double xt = __builtin_fma(dn, -k[1], x);
+    const double yt = __builtin_fma(dn, -pio2_m, xt);
+    const double ph = dn * pio2_m;
+    const double pt = __builtin_fma(dn, pio2_m, -ph);
     const double th = xt - ph;
     const double tt = (xt - th) - ph;
     const double c = ((th - yt) + tt) - pt;
-    const double d = __builtin_fma(dn, -0x1.b839a252049c0p-104, c);
+    const double d = __builtin_fma(dn, -k[3], c);
     const double hi = yt + d;
     const double lo = d - (hi - yt);
     const int q = (int)dn;
@@ -93,21 +124,21 @@ __device__ __forceinline__ void sincos_small(const double x, double& sn, double&
     const double c1 = 1.0 - h;
     const double c3 = (1.0 - c1) - h;
     const double t2 = t * t;
-    double p = __builtin_fma(t, -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29);
-    p = __builtin_fma(t, p, -0x1.27e4fa17f65f6p-22);
-    p = __builtin_fma(t, p, 0x1.a01a019f4ec90p-16);
-    p = __builtin_fma(t, p, -0x1.6c16c16c16967p-10);
-    p = __builtin_fma(t, p, 0x1.5555555555555p-5);
+    double p = __builtin_fma(t, k[4], k[5]);
+    p = __builtin_fma(t, p, k[6]);
+    p = __builtin_fma(t, p, k[7]);
+    p = __builtin_fma(t, p, k[8]);
+    p = __builtin_fma(t, p, k[9]);
     const double nlo = -lo;
     const double cq = __builtin_fma(t2, p, __builtin_fma(hi, nlo, c3));
     const double cosv = c1 + cq;
-    double s = __builtin_fma(t, 0x1.5e0b2f9a43bb8p-33, -0x1.ae600b42fdfa7p-26);
-    s = __builtin_fma(t, s, 0x1.71de3796cde01p-19);
-    s = __builtin_fma(t, s, -0x1.a01a019e83e5cp-13);
-    s = __builtin_fma(t, s, 0x1.1111111110bb3p-7);
+    double s = __builtin_fma(t, k[10], k[11]);
+    s = __builtin_fma(t, s, k[12]);
+    s = __builtin_fma(t, s, k[13]);
+    s = __builtin_fma(t, s, k[14]);
     const double v = hi * -t;
     const double w = __builtin_fma(t, __builtin_fma(v, s, lo * 0.5), nlo);
-    const double sinv = hi - __builtin_fma(v, -0x1.5555555555555p-3, w);
+    const double sinv = hi - __builtin_fma(v, k[15], w);
     // quadrant: sin <- (q odd ? cos : sin), cos <- (q odd ? -sin : cos); both negated for q & 2
     const bool odd = (q & 1) != 0;
     const int flip = (q & 2) ? (int)0x80000000 : 0;
@@ -115,6 +146,9 @@ __device__ __forceinline__ void sincos_small(const double x, double& sn, double&
     const double co = odd ? -sinv : cosv;
     sn = __hiloint2double(__double2hiint(so) ^ flip, __double2loint(so));
     cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
+}
+__device__ __forceinline__ void sincos_small(const double x, double& sn, double& cs) {
+    sincos_small_k(TrigFromRegs{}, x, sn, cs);
 }
 
 // ---- build-defined counter RNG; must agree with rtm_rng_u01 on the host ----

@@ -111,6 +111,17 @@ __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, i
     return normalize((P.ax * px + P.by * py) + P.cz);
 }
 
+// The same, with the nine camera-basis doubles read from an LDS block (cam[0..8] = ax, by, cz).  The
+// block is read once per sub-pixel; keeping those doubles in registers across the render loop made
+// hipcc spill them to scratch per lane (200 MB of stray HBM writes per 1080p frame).
+__device__ __forceinline__ D3 primary_dir_lds(const RenderParams& P, const double* cam, int x, int y, int sx,
+                                              int sy) {
+    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
+    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
+    const D3 ax = d3(cam[0], cam[1], cam[2]), by = d3(cam[3], cam[4], cam[5]), cz = d3(cam[6], cam[7], cam[8]);
+    return normalize((ax * px + by * py) + cz);
+}
+
 __device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsigned v) {
     unsigned long long s = v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -148,13 +159,28 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //   UNROLL  spheres whose geometry is fetched together (wave-uniform loads)
 //   RecT    hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged in LDS per lane
 // Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat n*8 doubles][records].
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1>
+//   PARK    the pixel accumulator and the cached primary direction live in LDS ([component][lane]),
+//           not in VGPRs: they are touched once per sample, and the 12 registers they would pin
+//           are what the unrolled sphere chunk needs to stay under 128 VGPRs without scratch spills
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
     double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
-    RecT* rec = reinterpret_cast<RecT*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
+    double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
+    double* trig = cam + 10;                 // 9 camera doubles + pad
+    double* park = trig + kTrigConstCount;   // 16 sincos constants
+    RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
+    if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
+    if (lane < 9) {
+        const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
+        double pick = v9[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) pick = (lane == k) ? v9[k] : pick;
+        cam[lane] = pick;
+    }
+    __syncthreads();
     if constexpr (LDS_TAB) {
         const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
         for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
@@ -181,11 +207,19 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     unsigned n = valid ? 0u : P.total_samples;  // sample index ((sx-1)*SS + (sy-1))*S + s
     int s_in_sub = 0, sub = 0;
-    D3 pdir = primary_dir(P, x, y, 1, 1);
+    D3 pdir = primary_dir_lds(P, cam, x, y, 1, 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
     const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
     RngStream rng = rng_open(pkey, 0u);
+    if constexpr (PARK) {
+        park[0 * 64 + lane] = 0.0;
+        park[1 * 64 + lane] = 0.0;
+        park[2 * 64 + lane] = 0.0;
+        park[3 * 64 + lane] = pdir.x;
+        park[4 * 64 + lane] = pdir.y;
+        park[5 * 64 + lane] = pdir.z;
+    }
 
     auto push = [&](int d, int id) { stack.push(d, id); };
     auto pop = [&](int d) -> int { return stack.pop(d); };
@@ -193,7 +227,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     while (n < P.total_samples) {
         D3 term;
-        bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
+        bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
         if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
             cont = false;
             term = d3(0, 0, 0);
@@ -209,20 +243,38 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
             // power-of-two divisors are applied as multiplications.
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
-            acc = acc + clamp01_d3(cal);  // :241-242
+            const D3 add = clamp01_d3(cal);
+            if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
+                park[0 * 64 + lane] += add.x;
+                park[1 * 64 + lane] += add.y;
+                park[2 * 64 + lane] += add.z;
+            } else {
+                acc = acc + add;
+            }
             ++n;
             if (++s_in_sub == P.S) {
                 s_in_sub = 0;
                 ++sub;
-                if (n < P.total_samples) pdir = primary_dir(P, x, y, sub / P.SS + 1, sub % P.SS + 1);
+                if (n < P.total_samples) {
+                    pdir = primary_dir_lds(P, cam, x, y, sub / P.SS + 1, sub % P.SS + 1);
+                    if constexpr (PARK) {
+                        park[3 * 64 + lane] = pdir.x;
+                        park[4 * 64 + lane] = pdir.y;
+                        park[5 * 64 + lane] = pdir.z;
+                    }
+                }
             }
             org = P.cam_org;
-            dir = pdir;
+            if constexpr (PARK)
+                dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
+            else
+                dir = pdir;
             depth = 0;
             rng = rng_open(pkey, n);
         }
     }
 
+    if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
     store_pixel(P, valid, x, y, acc);
     if (P.counters) {
         wave_add_counter(P.counters + 0, pc.casts);
@@ -695,9 +747,9 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 }
 
 // variant 0 = auto (the fastest parity-validated kernel for the scene size)
-static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8",
+static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8-park",
                                       "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
-                                      "fast-math-lds-tables-chunk8-occ5", "fast-math-lds-tables-chunk8-occ6",
+                                      "fast-math-lds-tables-chunk8-nopark", "fast-math-lds-tables-chunk8-occ6",
                                       "fast-math-lds-tables-chunk8-occ8"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
               kVariantSceneTiled = 4;
@@ -758,14 +810,15 @@ static size_t debug_lds_pad() {
     return pad;
 }
 
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1>
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + debug_lds_pad();
+    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
+                       (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad();
     constexpr int DEEP = deep_lds_levels<RecT>();
     if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
 template <typename RecT>
@@ -795,9 +848,9 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true>(P, grid, stream);
     } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 5>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, false>(P, grid, stream);
     } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
         launch_render_depth<MathFast, true, 8, uint8_t, 6>(P, grid, stream);
     } else if (variant == 7 && n <= kLdsTableMaxSpheres) {

@@ -116,6 +116,7 @@ struct MathFast {
 // per operation, and one long basic block for the scheduler.
 struct MathSpec {
     bool bad = false;
+    const double* trig_lds = nullptr;  // LDS copy of the sincos constants (optional)
     __device__ __forceinline__ double sqrt64(double x) {
         bad = bad || !MathFast::sqrt_fast_ok(x);
         const double y = __builtin_amdgcn_rsq(x);
@@ -142,14 +143,26 @@ struct MathSpec {
         };
         return D3{one(a.x), one(a.y), one(a.z)};
     }
-    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos_small(x, sn, cs); }
+    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) {
+        if (trig_lds)
+            sincos_small_k(TrigFromLds{trig_lds}, x, sn, cs);
+        else
+            sincos_small(x, sn, cs);
+    }
 };
 // instance adaptors so that path_shade can take any policy as an object
 struct MathRefI {
     static constexpr bool bad = false;
+    const double* trig_lds = nullptr;
     __device__ __forceinline__ double sqrt64(double x) { return MathRef::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathRef::div3(a, y); }
-    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
+    // r1 = 2*pi*u < 2^30 always: ocml's small-argument sequence IS ::sincos there (bit-identical)
+    __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) {
+        if (trig_lds)
+            sincos_small_k(TrigFromLds{trig_lds}, x, sn, cs);
+        else
+            sincos(x, &sn, &cs);
+    }
 };
 struct MathFastI {
     static constexpr bool bad = false;
@@ -411,12 +424,14 @@ __device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const 
 template <class Scene, typename PushFn>
 __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, const double dis, const int mode,
                                                 const int max_bounces, D3& org, D3& dir, int& depth,
-                                                RngStream& rng, D3& term, PathCounters& pc, PushFn push) {
+                                                RngStream& rng, D3& term, PathCounters& pc, PushFn push,
+                                                const double* trig_lds = nullptr) {
     const D3 org0 = org, dir0 = dir;
     const int depth0 = depth;
     const RngStream rng0 = rng;
     const PathCounters pc0 = pc;
     MathSpec m;
+    m.trig_lds = trig_lds;
     bool cont = path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
     if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
         org = org0;
@@ -425,6 +440,7 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
         rng = rng0;
         pc = pc0;
         MathRefI r;
+        r.trig_lds = trig_lds;
         cont = path_shade_with(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
     }
     return cont;
@@ -434,11 +450,11 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
 template <class M, int UNROLL, class Scene, typename PushFn>
 __device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const int max_bounces,
                                           D3& org, D3& dir, int& depth, RngStream& rng, D3& term,
-                                          PathCounters& pc, PushFn push) {
+                                          PathCounters& pc, PushFn push, const double* trig_lds = nullptr) {
     double dis;
     const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
     if constexpr (std::is_same<M, MathFast>::value)
-        return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+        return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push, trig_lds);
     else
         return path_shade<M>(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
 }
