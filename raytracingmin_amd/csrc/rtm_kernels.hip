@@ -58,7 +58,16 @@ struct RenderParams {
     unsigned* __restrict__ pool_next;       // bump allocator
     unsigned pool_slots;
     unsigned debug_flags;  // diagnostics only (RTM_DEBUG_FLAGS): bit 0 = skip the fold (WRONG image)
+    unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
 };
+
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
 
 constexpr int kPoolLevels = 960;  // records per pool slot beyond the LDS levels
 
@@ -162,7 +171,10 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //   PARK    the pixel accumulator and the cached primary direction live in LDS ([component][lane]),
 //           not in VGPRs: they are touched once per sample, and the 12 registers they would pin
 //           are what the unrolled sphere chunk needs to stay under 128 VGPRs without scratch spills
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false>
+//   STAMP   diagnostic build: s_memtime around the three segments of an iteration (never timed itself)
+//   PACK8   max_bounces <= 8 and n <= 256: hit records packed in a 64-bit register, no LDS stack
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
+          bool STAMP = false, bool PACK8 = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -221,13 +233,31 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         park[5 * 64 + lane] = pdir.z;
     }
 
-    auto push = [&](int d, int id) { stack.push(d, id); };
+    unsigned long long recq = 0;  // PACK8 records, most recent bounce in the low byte
+    auto push = [&](int d, int id) {
+        if constexpr (PACK8)
+            recq = (recq << 8) | (unsigned long long)(unsigned)id;
+        else
+            stack.push(d, id);
+    };
     auto pop = [&](int d) -> int { return stack.pop(d); };
     const bool pow2 = P.inv_s != 0.0;  // wave-uniform
 
+    unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
     while (n < P.total_samples) {
         D3 term;
-        bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+        bool cont;
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if constexpr (STAMP) {
+            ts0 = stamp_now();
+            double dis;
+            const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+            ts1 = stamp_now();
+            cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+            ts2 = stamp_now();
+        } else {
+            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+        }
         if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
             cont = false;
             term = d3(0, 0, 0);
@@ -236,10 +266,14 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         if (!cont) {
             // all ending lanes within the LDS levels (always, when max_bounces < 16): blocked fold
             const bool deep = depth > LDS_D;
-            const D3 L = (P.debug_flags & 1u) ? term
-                         : (__builtin_amdgcn_ballot_w64(deep) == 0)
-                             ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
-                             : path_fold(sc, term, depth, pop);
+            D3 L;
+            if constexpr (PACK8)
+                L = path_fold_packed8(sc, term, depth, recq);
+            else
+                L = (P.debug_flags & 1u) ? term
+                    : (__builtin_amdgcn_ballot_w64(deep) == 0)
+                        ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
+                        : path_fold(sc, term, depth, pop);
             // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
             // power-of-two divisors are applied as multiplications.
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
@@ -271,6 +305,21 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 dir = pdir;
             depth = 0;
             rng = rng_open(pkey, n);
+        }
+        if constexpr (STAMP) {
+            const unsigned long long ts3 = stamp_now();
+            st_near += ts1 - ts0;
+            st_shade += ts2 - ts1;
+            st_end += ts3 - ts2;
+            st_iters += 1;
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && P.stamps) {
+            P.stamps[blockIdx.x * 4 + 0] = st_near;
+            P.stamps[blockIdx.x * 4 + 1] = st_shade;
+            P.stamps[blockIdx.x * 4 + 2] = st_end;
+            P.stamps[blockIdx.x * 4 + 3] = st_iters;
         }
     }
 
@@ -747,10 +796,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 }
 
 // variant 0 = auto (the fastest parity-validated kernel for the scene size)
-static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8-park",
+static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8-park-pack8",
                                       "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
-                                      "fast-math-lds-tables-chunk8-nopark", "fast-math-lds-tables-chunk8-occ6",
-                                      "fast-math-lds-tables-chunk8-occ8"};
+                                      "fast-math-lds-tables-chunk8-nopark-pack8", "fast-math-lds-tables-chunk8-park-ldsrecords",
+                                      "diagnostic-stamped (segment cycle shares, not for timing)"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
               kVariantSceneTiled = 4;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
@@ -810,15 +859,22 @@ static size_t debug_lds_pad() {
     return pad;
 }
 
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false>
+template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
+          bool TRY_PACK8 = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad();
     constexpr int DEEP = deep_lds_levels<RecT>();
+    if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
+        if (P.max_bounces >= 0 && P.max_bounces <= 8) {
+            render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true><<<grid, 64, tab, stream>>>(P);
+            return;
+        }
+    }
     if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
 template <typename RecT>
@@ -848,13 +904,13 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
     } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, false>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, false, false, true>(P, grid, stream);
     } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 6>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, false>(P, grid, stream);
     } else if (variant == 7 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 8>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true>(P, grid, stream);
     } else {
         if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
         else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
@@ -904,6 +960,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     } pool_free{pool, stream};
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
+    unsigned long long* stamps = nullptr;
+    if (opt->variant == 7) {
+        RTM_HIP_CHECK(hipMalloc((void**)&stamps, (size_t)grid * 4 * sizeof(unsigned long long)));
+        RTM_HIP_CHECK(hipMemset(stamps, 0, (size_t)grid * 4 * sizeof(unsigned long long)));
+        P.stamps = stamps;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
@@ -913,6 +975,18 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     }
     launch_render(opt->variant, P, grid, tiles_y, stream);
     RTM_HIP_CHECK(hipGetLastError());
+    if (stamps) {  // diagnostic variant: print the per-wave segment shares
+        RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h((size_t)grid * 4);
+        RTM_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double a[4] = {0, 0, 0, 0};
+        for (size_t b = 0; b < grid; ++b)
+            for (int k = 0; k < 4; ++k) a[k] += (double)h[b * 4 + k];
+        std::fprintf(stderr,
+                     "[rtm stamps] per wave-iteration cycles: nearest %.0f, shade %.0f, end+loop %.0f (iterations/wave %.0f)\n",
+                     a[0] / a[3], a[1] / a[3], a[2] / a[3], a[3] / grid);
+        (void)hipFree(stamps);
+    }
     if (stats) {
         RTM_HIP_CHECK(hipEventRecord(ev1, stream));
         unsigned long long c[4];

@@ -333,9 +333,9 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
             }
         }
     } else {
-        static_assert(UNROLL == 8, "chunked form is written for chunks of 8 plus an exact tail");
+        static_assert(UNROLL == 8 || UNROLL == 4, "chunks of 8 or 4 plus an exact tail");
         int i0 = 0;
-        for (; i0 + 8 <= n; i0 += 8) sphere_chunk<M, 8>(sc, i0, org, dir, dis, hit_object);
+        for (; i0 + UNROLL <= n; i0 += UNROLL) sphere_chunk<M, UNROLL>(sc, i0, org, dir, dis, hit_object);
         switch (n - i0) {  // wave-uniform: exactly one tail chunk, sized to the remainder
             case 1: sphere_chunk<M, 1>(sc, i0, org, dir, dis, hit_object); break;
             case 2: sphere_chunk<M, 2>(sc, i0, org, dir, dis, hit_object); break;
@@ -497,6 +497,34 @@ __device__ __forceinline__ D3 path_fold_blocked(const Scene& sc, const D3 term, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
         d -= 4;
+    }
+    return L;
+}
+
+// Fold for paths of at most eight bounces whose records are packed in one 64-bit register, the most
+// recent bounce in the low byte (n_spheres <= 256): no LDS traffic for the records at all.  Two
+// groups of four levels; the second is skipped when no ending lane is deeper than four.
+template <class Scene>
+__device__ __forceinline__ D3 path_fold_packed8(const Scene& sc, const D3 term, const int depth,
+                                                const unsigned long long rec) {
+    D3 L = term;
+    const int identity = sc.n();
+    const unsigned lo = (unsigned)rec, hi = (unsigned)(rec >> 32);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (g == 1 && __builtin_amdgcn_ballot_w64(depth > 4) == 0) break;
+        const unsigned word = g ? hi : lo;
+        int id[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) id[k] = (g * 4 + k < depth) ? (int)((word >> (8 * k)) & 0xFFu) : identity;
+        D3 c[4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = sc.color_kd(id[k]);
+            e[k] = sc.emission(id[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
     }
     return L;
 }
