@@ -185,6 +185,11 @@ def main():
         rows0 = sr.rows[1] - sr.rows[0]
         alg_bytes = rows0 * cfg["width"] * 12 + n_spheres * 96
         hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        headline = all(cfg[k] == HEADLINE[k] for k in ("width", "height", "samples", "super_samples", "max_bounces"))
+        if world == 1 and headline and args.variant == 0 and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["bytes_per_launch"]  # measured PMC bytes, committed profile
         line = {
             "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp", "value": value,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +203,7 @@ def main():
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": traffic,
                 "kernel": "render_tiles_kernel", "kernel_ms": kernel_ms,
                 "flops_per_sample": f_sample,
                 "note": "no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM "

@@ -207,9 +207,17 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         sc.lmat = lmat;
     }
 
-    const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
-    const int x = tx * 8 + (lane & 7);
-    const int y = P.row_begin + ty * 8 + (lane >> 3);
+    // Pixel coordinates are recomputed where they are needed (sub-pixel change, final store) from an
+    // opaque copy of the lane id, so that nothing derived from them stays live across the render loop.
+    auto pixel_xy = [&](int& px, int& py) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+        px = tx * 8 + (l & 7);
+        py = P.row_begin + ty * 8 + (l >> 3);
+    };
+    int x, y;
+    pixel_xy(x, y);
     const bool valid = (x < P.W) && (y < P.row_end);
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;  // GLOBAL pixel index
 
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     D3 acc = d3(0, 0, 0);
 
     unsigned n = valid ? 0u : P.total_samples;  // sample index ((sx-1)*SS + (sy-1))*S + s
-    int s_in_sub = 0, sub = 0;
+    int left_in_sub = P.S;                      // samples left before the sub-pixel changes
     D3 pdir = primary_dir_lds(P, cam, x, y, 1, 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
@@ -286,11 +294,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 acc = acc + add;
             }
             ++n;
-            if (++s_in_sub == P.S) {
-                s_in_sub = 0;
-                ++sub;
+            if (--left_in_sub == 0) {
+                left_in_sub = P.S;
                 if (n < P.total_samples) {
-                    pdir = primary_dir_lds(P, cam, x, y, sub / P.SS + 1, sub % P.SS + 1);
+                    const int sub = (int)(n / (unsigned)P.S);
+                    int px, py;
+                    pixel_xy(px, py);
+                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
                     if constexpr (PARK) {
                         park[3 * 64 + lane] = pdir.x;
                         park[4 * 64 + lane] = pdir.y;
@@ -324,7 +334,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 
     if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
-    store_pixel(P, valid, x, y, acc);
+    {
+        int px, py;
+        pixel_xy(px, py);
+        store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
+    }
     if (P.counters) {
         wave_add_counter(P.counters + 0, pc.casts);
         wave_add_counter(P.counters + 1, pc.bounces);
