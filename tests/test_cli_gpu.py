@@ -1,0 +1,66 @@
+"""rtm_cli — the reference's main() over the C ABI (-m gpu): shipped scene files run unchanged and the
+files written match the oracle's quantised image."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "raytracingmin_amd", "rtm_cli")
+
+
+def test_cli_renders_shipped_scene_and_writes_both_files(tmp_path, oracle):
+    from PIL import Image
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    stem = str(tmp_path / "result")
+    w, h, s, ss = 96, 56, 64, 2  # 256 spp: smooth enough for a meaningful JPEG comparison
+    r = subprocess.run([CLI, "-json", scene, "--width", str(w), "--height", str(h), "--samples", str(s),
+                        "--superSamples", str(ss), "--max-bounces", "8", "--seed", "24301", "--out", stem],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Msamples/s" in r.stdout
+    bmp = np.array(Image.open(stem + ".bmp"))
+    jpg = np.array(Image.open(stem + ".jpg").convert("RGB"))
+    assert bmp.shape == (h, w, 3) and jpg.shape == (h, w, 3)
+    st, arr, n = oracle.load_scene(scene, width=w, height=h, samples=s, super_samples=ss)
+    ref, _ = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=8, seed=24301, height=h))
+    want = oracle.quantise(ref)
+    assert np.mean(bmp != want) < 1e-3  # identical but for a possible last-ulp truncation flip
+    # quality-60 4:2:0 JPEG of the same pixels: compare 8x8 block means (the frame still has noise)
+    bm = lambda a: a[:h // 8 * 8, :w // 8 * 8].astype(float).reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(bm(jpg) - bm(want)).mean() < 4 and np.abs(jpg.astype(int) - want.astype(int)).mean() < 12
+
+
+def test_cli_literal_mode_matches_reference_golden(tmp_path, oracle):
+    """HEAD as shipped (L0) on the shipped Cornell file: the white-disc image of SURVEY §0.3."""
+    from PIL import Image
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    stem = str(tmp_path / "lit")
+    r = subprocess.run([CLI, "-json", scene, "--width", "128", "--height", "128", "--samples", "8",
+                        "--superSamples", "2", "--mode", "literal", "--out", stem],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    bmp = np.array(Image.open(stem + ".bmp")).reshape(-1, 3)
+    white = (bmp == 255).all(axis=1)
+    assert int(white.sum()) == 1100 and not bmp[~white].any()  # golden of tests/golden/survey_8c.json
+
+
+def test_cli_flags_of_the_reference(tmp_path):
+    r = subprocess.run([CLI, "-?"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "-sampleJson" in r.stdout and "-json" in r.stdout
+    r = subprocess.run([CLI, "-sampleJson"], capture_output=True, text=True, cwd=tmp_path, timeout=30)
+    assert r.returncode == 0
+    j = json.load(open(tmp_path / "settingData.json"))
+    assert (j["00 width"], j["00 height"], j["00 samples"], j["00 superSamples"]) == (960, 540, 10, 4)
+    # default run: no -json => settingData.json (just written, no scene) => a black 64x36 frame
+    r = subprocess.run([CLI, "--width", "64", "--height", "36", "--samples", "1", "--superSamples", "1"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from PIL import Image
+    assert not np.array(Image.open(tmp_path / "result.bmp")).any()
+    assert os.path.exists(tmp_path / "result.jpg")
+    bad = subprocess.run([CLI, "-json", "/nonexistent/dir/x.json"], capture_output=True, text=True, timeout=30)
+    assert bad.returncode != 0
