@@ -3,6 +3,7 @@
 //   rtm_cli [-?] [-json <file>] [-sampleJson]            (the reference's flags, same defaults)
 //           [--width N] [--height N] [--samples N] [--superSamples N] [--spp N]
 //           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM]
+//           [--gpus N] [--virtual-strips N]      (row strips over N GPUs + one RCCL gather)
 //
 // Flow of the reference: pick the JSON (default settingData.json), create the sample JSON when it
 // does not exist, load, render, write <stem>.jpg (quality 60) and <stem>.bmp with stem "result".
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rtm.h"
+#include "rtm_node.h"
 
 static bool file_exists(const std::string& p) {
     FILE* f = std::fopen(p.c_str(), "rb");
@@ -29,13 +31,14 @@ static void usage() {
         "--width/--height/--samples/--superSamples N : override the file's values\n"
         "--spp N : samples = N / superSamples^2\n"
         "--mode literal|repaired (default repaired), --max-bounces N (default -1 = unlimited)\n"
-        "--seed N, --device N, --out STEM (default result)\n");
+        "--seed N, --device N, --out STEM (default result)\n"
+        "--gpus N : row strips over N GPUs of this node, one RCCL gather; --virtual-strips N : N strips on one GPU\n");
 }
 
 int main(int argc, char* argv[]) {
     std::string json_file = "settingData.json", stem = "result";
     int width = 0, height = 0, samples = 0, super_samples = 0, spp = 0;
-    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0;
+    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0;
     unsigned long long seed = 0x5EED;
     for (int i = 1; i < argc; ++i) {
         const std::string c = argv[i];
@@ -60,6 +63,8 @@ int main(int argc, char* argv[]) {
         else if (c == "--spp") next_int(spp);
         else if (c == "--max-bounces") next_int(max_bounces);
         else if (c == "--device") next_int(device);
+        else if (c == "--gpus") next_int(gpus);
+        else if (c == "--virtual-strips") next_int(virtual_strips);
         else if (c == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
         else if (c == "--out" && i + 1 < argc) stem = argv[++i];
         else if (c == "--mode" && i + 1 < argc) {
@@ -110,10 +115,24 @@ int main(int argc, char* argv[]) {
     const size_t vals = (size_t)st.width * st.height * 3;
     std::vector<uint8_t> rgb8(vals);
     rtm_stats stats;
-    rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, nullptr, rgb8.data(), &stats);
-    if (rc != RTM_OK) {
-        std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), rtm_last_error_detail());
-        return 1;
+    if (gpus > 1 || virtual_strips > 0) {
+        int have = 0;
+        if (rtm_device_count(&have) != RTM_OK || have < gpus) {
+            std::fprintf(stderr, "--gpus %d requested, %d HIP device(s) present\n", gpus, have);
+            return 1;
+        }
+        std::string err;
+        rc = rtm_node_render_u8(&st, spheres.data(), n, &opt, gpus, virtual_strips, rgb8.data(), &stats, err);
+        if (rc != RTM_OK) {
+            std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), err.c_str());
+            return 1;
+        }
+    } else {
+        rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, nullptr, rgb8.data(), &stats);
+        if (rc != RTM_OK) {
+            std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), rtm_last_error_detail());
+            return 1;
+        }
     }
     std::printf("%d x %d, %llu samples, %.3f casts/sample, kernel %.3f ms, %.1f Msamples/s\n", st.width,
                 st.height, (unsigned long long)stats.samples,

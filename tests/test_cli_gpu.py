@@ -64,3 +64,19 @@ def test_cli_flags_of_the_reference(tmp_path):
     assert os.path.exists(tmp_path / "result.jpg")
     bad = subprocess.run([CLI, "-json", "/nonexistent/dir/x.json"], capture_output=True, text=True, timeout=30)
     assert bad.returncode != 0
+
+
+def test_cli_strip_tiling_equals_single_render(tmp_path, oracle):
+    """The host program's N-strip path (one strip per GPU + one RCCL gather on a multi-GPU node; here
+    N virtual strips on the one GPU through the same partition/assembly code) writes the same file."""
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    args = [CLI, "-json", scene, "--width", "88", "--height", "50", "--samples", "2", "--superSamples", "2",
+            "--max-bounces", "8", "--seed", "7"]
+    a = subprocess.run(args + ["--out", str(tmp_path / "one")], capture_output=True, text=True, timeout=120)
+    b = subprocess.run(args + ["--virtual-strips", "3", "--out", str(tmp_path / "three")], capture_output=True,
+                       text=True, timeout=120)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert open(tmp_path / "one.bmp", "rb").read() == open(tmp_path / "three.bmp", "rb").read()
+    assert open(tmp_path / "one.jpg", "rb").read() == open(tmp_path / "three.jpg", "rb").read()
+    many = subprocess.run(args + ["--gpus", "64"], capture_output=True, text=True, timeout=60)
+    assert many.returncode != 0 and "HIP device" in many.stderr
