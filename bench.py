@@ -87,6 +87,10 @@ def main():
     ap.add_argument("--super-samples", type=int, default=HEADLINE["super_samples"])
     ap.add_argument("--max-bounces", type=int, default=HEADLINE["max_bounces"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs: c2 Cornell 512x512x256spp, c3 headline (default), c4 Cornell 4K x 4096spp, "
+                         "c5 100k-sphere stress scene 1080p x 256spp (use --rows to bound it)")
+    ap.add_argument("--rows", default="", help="render only rows a:b of the frame (value counts those samples)")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -110,15 +114,28 @@ def main():
 
     cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
                super_samples=args.super_samples, max_bounces=args.max_bounces)
-    scene = os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"])
-    data = rtm.LoadData(scene).data
+    if args.workload == "c2":
+        cfg.update(width=512, height=512, samples=16, super_samples=4)
+    elif args.workload == "c4":
+        cfg.update(width=3840, height=2160, samples=256, super_samples=4)
+    elif args.workload == "c5":
+        cfg.update(scene="stress-100k (SURVEY App. D, seed 12345)", width=1920, height=1080, samples=256, super_samples=1)
+    if args.workload == "c5":
+        data = rtm.make_stress_scene(n=100_000, seed=12345)
+    else:
+        scene = os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"])
+        data = rtm.LoadData(scene).data
     data.width, data.height = cfg["width"], cfg["height"]
     data.samples, data.superSamples = cfg["samples"], cfg["super_samples"]
     spp = cfg["samples"] * cfg["super_samples"] ** 2
+    row_lo, row_hi = 0, cfg["height"]
+    if args.rows:
+        row_lo, row_hi = (int(v) for v in args.rows.split(":"))
 
     from raytracingmin_amd.distributed import StripRenderer
     sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
-                       max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant)
+                       max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant,
+                       rows=(row_lo, row_hi))
 
     if args.ab:
         # interleaved rounds in ONE process (guide rule 24): median/min kernel ms per variant
@@ -166,7 +183,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    total_samples = cfg["width"] * cfg["height"] * spp
+    total_samples = cfg["width"] * (row_hi - row_lo) * spp
     value = total_samples * args.steps / elapsed / 1e6
 
     if rank == 0:
@@ -187,7 +204,8 @@ def main():
         hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        headline = all(cfg[k] == HEADLINE[k] for k in ("width", "height", "samples", "super_samples", "max_bounces"))
+        headline = args.workload == "c3" and not args.rows and \
+            all(cfg[k] == HEADLINE[k] for k in ("width", "height", "samples", "super_samples", "max_bounces"))
         if world == 1 and headline and args.variant == 0 and os.path.exists(tpath):
             traffic = json.load(open(tpath))["bytes_per_launch"]  # measured PMC bytes, committed profile
         line = {
@@ -195,7 +213,7 @@ def main():
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"ExampleScene/cornellBoxSetting.json {cfg['width']}x{cfg['height']} "
+            "config": {"workload": f"{cfg['scene']} rows {row_lo}:{row_hi} of {cfg['width']}x{cfg['height']} "
                                    f"{spp}spp (SS {cfg['super_samples']} x S {cfg['samples']}), L1 repaired, "
                                    f"max_bounces {cfg['max_bounces']}, seed 0x5EED, row strips over "
                                    f"{world} GPU(s) + one gather",

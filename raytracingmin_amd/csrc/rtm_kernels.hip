@@ -57,7 +57,6 @@ struct RenderParams {
     unsigned char* __restrict__ pool;       // pool_slots x kPoolLevels records
     unsigned* __restrict__ pool_next;       // bump allocator
     unsigned pool_slots;
-    unsigned debug_flags;  // diagnostics only (RTM_DEBUG_FLAGS): bit 0 = skip the fold (WRONG image)
     unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
 };
 
@@ -278,8 +277,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if constexpr (PACK8)
                 L = path_fold_packed8(sc, term, depth, recq);
             else
-                L = (P.debug_flags & 1u) ? term
-                    : (__builtin_amdgcn_ballot_w64(deep) == 0)
+                L = (__builtin_amdgcn_ballot_w64(deep) == 0)
                         ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
                         : path_fold(sc, term, depth, pop);
             // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
@@ -415,14 +413,20 @@ __global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderPar
                     pre[k] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
                 }
             }
-            const double2* cur = tile_buf + (t & 1) * TILE * 2;
             const int base = t * TILE;
             const int cnt = (n - base < TILE) ? (n - base) : TILE;
-#pragma unroll 4
-            for (int j = 0; j < cnt; ++j) {
-                const double2 a = cur[2 * j], b = cur[2 * j + 1];  // same address in every lane
-                sphere_update<M>(double4{a.x, a.y, b.x, b.y}, org, dir, base + j, dis, id);
-            }
+            // the tile as a "scene": every lane reads the same LDS address per sphere (broadcast)
+            struct TileGeom {
+                const double2* cur;
+                int base;
+                __device__ __forceinline__ double4 geom_uniform(int i) const {
+                    const double2 a = cur[2 * (i - base)], b = cur[2 * (i - base) + 1];
+                    return double4{a.x, a.y, b.x, b.y};
+                }
+            } tile{tile_buf + (t & 1) * TILE * 2, base};
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) sphere_chunk<M, 8, TileGeom, true>(tile, base + j, org, dir, dis, id);
+            for (; j < cnt; ++j) sphere_chunk<M, 1, TileGeom, true>(tile, base + j, org, dir, dis, id);
             if (more) {
                 double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
 #pragma unroll
@@ -855,7 +859,6 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.by = D3{cam_y.x * fovy, cam_y.y * fovy, cam_y.z * fovy};  // l_camY * fovy, :230
     P.cz = D3{direction.x, direction.y, direction.z};
     P.seed_mult = seed_multiplier(opt->seed);
-    if (const char* e = std::getenv("RTM_DEBUG_FLAGS")) P.debug_flags = (unsigned)std::strtoul(e, nullptr, 0);
 }
 
 // LDS record levels: 16 when the cap guarantees depth < 16; otherwise 64 (u8) / 32 (u32) levels in
@@ -924,7 +927,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
         launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, false>(P, grid, stream);
     } else if (variant == 7 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true>(P, grid, stream);
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true, true>(P, grid, stream);
     } else {
         if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
         else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);

@@ -294,7 +294,9 @@ __device__ __forceinline__ void sphere_update(const double4 g, const D3 org, con
 // wave-uniform guard, then the K acceptance updates in index order (strict <: the lowest index still
 // wins ties).  Select-only form, see sphere_update for the equivalence with the statement order.
 // profiles/ubench/nearest_variants.hip: 36 % fewer cycles per cast than the per-sphere loop.
-template <class M, int K, class Scene>
+// EARLY_OUT (scenes of many small spheres): when no lane of the wave has D4 >= 0 for any sphere of
+// the chunk — the common case there — the square roots and updates are skipped altogether.
+template <class M, int K, class Scene, bool EARLY_OUT = false>
 __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
                                              double& dis, int& hit_object) {
     double b[K], D4[K], sq[K];
@@ -304,6 +306,12 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
         const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
         b[k] = dot(p_o, dir);                                      // :199
         D4[k] = b[k] * b[k] - dot(p_o, p_o) + g.w;                 // :200
+    }
+    if constexpr (EARLY_OUT) {
+        bool any = false;  // a NaN discriminant (literal mode) is "not >= 0": it can never be accepted
+#pragma unroll
+        for (int k = 0; k < K; ++k) any = any || (D4[k] >= 0.0);
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
     }
     M::template sqrt64_batch<K>(D4, sq);                           // :205 (D4 < 0 gives NaN: no hit)
 #pragma unroll

@@ -52,10 +52,11 @@ class StripRenderer:
     """Rank-local renderer of one row strip plus the end-of-step gather (bench.py's step)."""
 
     def __init__(self, data, rank=0, world=1, device=0, mode="repaired", max_bounces=-1,
-                 seed=0x5EED, variant=0, want="f32"):
+                 seed=0x5EED, variant=0, want="f32", rows=None):
         from .renderer import Renderer
         self.data, self.rank, self.world = data, rank, world
-        self.strips = partition_rows(data.height, world)
+        lo, hi = rows if rows else (0, data.height)
+        self.strips = [(lo + b, lo + e) for b, e in partition_rows(hi - lo, world)]
         self.rows = self.strips[rank]
         self.want = want
         self.renderer = Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, device=device,
