@@ -247,7 +247,7 @@ static inline uint64_t smfin64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-/* pixel key: one 64-bit mix per pixel; sample key: one 32-bit mix; draw: two 32-bit mixes */
+/* pixel key: one 64-bit mix per pixel; sample key: two 32-bit mixes; draw: one 32-bit mix */
 typedef struct rng_stream {
     uint32_t k0, k1, index;
     rtmo_counters* c;
@@ -260,12 +260,11 @@ static inline void stream_init(rng_stream* s, uint64_t seed_mult, uint32_t pixel
     const uint64_t z = smfin64(((uint64_t)pixel + 1ull) * seed_mult);
     const uint32_t p0 = (uint32_t)z, p1 = (uint32_t)(z >> 32);
     s->k0 = mix32(p0 + sample * 0x9E3779B9u);
-    s->k1 = p1 ^ (sample * 0x85EBCA6Bu);
+    s->k1 = mix32(p1 ^ (sample * 0x85EBCA6Bu));
     s->index = 0;
 }
 static inline double stream_u01(uint32_t k0, uint32_t k1, uint32_t index) {
-    uint32_t x = mix32(k0 + index * 0x9E3779B9u);
-    x = mix32(x ^ k1);
+    const uint32_t x = mix32((k0 + index * 0x9E3779B9u) ^ k1);
     /* 23 random bits, never 0 or 1, exact in fp32 and fp64 */
     return (double)(2u * (x >> 9) + 1u) * (1.0 / 16777216.0);
 }

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtm_hip.so")
+LIB_PATH = os.environ.get("RTM_LIB_OVERRIDE") or os.path.join(_HERE, "librtm_hip.so")  # override: A/B of builds
 
 RTM_OK = 0
 MODE_LITERAL, MODE_REPAIRED = 0, 1

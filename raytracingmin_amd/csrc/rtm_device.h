@@ -168,10 +168,10 @@ __host__ __device__ __forceinline__ uint64_t smfin64(uint64_t z) {
 __host__ __device__ __forceinline__ uint64_t seed_multiplier(uint64_t seed) {
     return smfin64(seed + 0x9E3779B97F4A7C15ull) | 1ull;
 }
-// Keying: one 64-bit mix per PIXEL, one 32-bit mix per SAMPLE, two 32-bit mixes per DRAW.
+// Keying: one 64-bit mix per PIXEL, one 32-bit mix per SAMPLE, one 32-bit mix per DRAW.
 //   pixel key   (p0, p1) = halves of smfin64((pixel + 1) * seed_mult)
-//   sample key  k0 = mix32(p0 + sample * 0x9E3779B9), k1 = p1 ^ (sample * 0x85EBCA6B)
-//   draw j      bits = mix32(mix32(k0 + j * 0x9E3779B9) ^ k1);  u = (2 * (bits >> 9) + 1) * 2^-24
+//   sample key  k0 = mix32(p0 + sample * 0x9E3779B9), k1 = mix32(p1 ^ (sample * 0x85EBCA6B))
+//   draw j      bits = mix32((k0 + j * 0x9E3779B9) ^ k1);  u = (2 * (bits >> 9) + 1) * 2^-24
 struct RngPixelKey {
     uint32_t p0, p1;
 };
@@ -183,14 +183,14 @@ __host__ __device__ __forceinline__ RngPixelKey rng_pixel_key(uint64_t seed_mult
     return RngPixelKey{(uint32_t)z, (uint32_t)(z >> 32)};
 }
 __host__ __device__ __forceinline__ RngStream rng_open(RngPixelKey pk, uint32_t sample) {
-    return RngStream{mix32(pk.p0 + sample * 0x9E3779B9u), pk.p1 ^ (sample * 0x85EBCA6Bu)};
+    return RngStream{mix32(pk.p0 + sample * 0x9E3779B9u), mix32(pk.p1 ^ (sample * 0x85EBCA6Bu))};
 }
 __host__ __device__ __forceinline__ double rng_bits_to_u01(uint32_t x) {
     // 23 random bits -> odd multiple of 2^-24: never 0 or 1, exact in fp32 and fp64
     return (double)(2u * (x >> 9) + 1u) * (1.0 / 16777216.0);
 }
 __host__ __device__ __forceinline__ double rng_next(RngStream& s) {
-    const uint32_t x = mix32(mix32(s.ctr) ^ s.k1);
+    const uint32_t x = mix32(s.ctr ^ s.k1);
     s.ctr += 0x9E3779B9u;
     return rng_bits_to_u01(x);
 }

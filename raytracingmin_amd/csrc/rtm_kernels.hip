@@ -109,8 +109,8 @@ struct RecordStack {
 };
 
 // LDS copy of the scene tables: n geometry rows (4 doubles) + n+1 material rows (8 doubles, the last
-// one is the identity row), rounded up to 16 bytes
-__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 4 + ((size_t)n + 1) * 8) * sizeof(double); }
+// one is the identity row) + n normal-length rows (2 doubles)
+__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 6 + ((size_t)n + 1) * 8) * sizeof(double); }
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
 __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     const int lane = threadIdx.x;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
     double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
+    double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
     double* park = trig + kTrigConstCount;   // 16 sincos constants
@@ -196,6 +197,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
         for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
         for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
+        for (int i = lane; i < P.scene.n; i += 64) {
+            const double ms = (double)__builtin_sqrtf((float)gsrc[i * 4 + 3]);
+            lnrm[i * 2] = ms;
+            lnrm[i * 2 + 1] = refined_rcp_or_nan(ms);
+        }
         __syncthreads();  // one wave per block: orders the LDS writes before the reads
     }
     using Scene = typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type;
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     if constexpr (LDS_TAB) {
         sc.lgeom = lgeom;
         sc.lmat = lmat;
+        sc.lnrm = lnrm;
     }
 
     // Pixel coordinates are recomputed where they are needed (sub-pixel change, final store) from an

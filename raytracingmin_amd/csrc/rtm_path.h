@@ -149,7 +149,34 @@ struct MathSpec {
         else
             sincos_small(x, sn, cs);
     }
+    // Normalize(hit - centre) (src/SettingData.cpp:214-215) for a hit point that is ON its sphere to
+    // float precision: then (float)|dv|^2 is exactly (float)(r*r), so Magnitude returns the
+    // per-sphere constant `ms` and the reciprocal refinement of the three divisions is the
+    // per-sphere constant `rinv` (both precomputed with the same instruction sequence).  Taken only
+    // when every active lane is in that case; otherwise the general Normalize runs.
+    __device__ __forceinline__ D3 normalize_on_sphere(D3 dv, double ms, double rinv, float r2f) {
+        const float len2f = (float)(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
+        const bool canon = (len2f == r2f) && (rinv == rinv);
+        if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3(dv, (double)__builtin_sqrtf(len2f));
+        bad = bad || !(MathFast::moderate(dv.x) && MathFast::moderate(dv.y) && MathFast::moderate(dv.z));
+        auto one = [&](double x) {
+            const double q = x * rinv;
+            const double rem = __builtin_fma(-ms, q, x);
+            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, rinv, q), ms, x);
+        };
+        return D3{one(dv.x), one(dv.y), one(dv.z)};
+    }
 };
+// the reciprocal refinement MathFast/MathSpec::div3 apply to a denominator (v_rcp_f64 + two
+// Newton steps), or NaN when the denominator is outside their exact range
+__device__ __forceinline__ double refined_rcp_or_nan(double y) {
+    if (!MathFast::moderate(y) || y == 0.0) return __builtin_nan("");
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
 // instance adaptors so that path_shade can take any policy as an object
 struct MathRefI {
     static constexpr bool bad = false;
@@ -209,6 +236,7 @@ __device__ __forceinline__ double4 load_geom_uniform(const double4* geom, int i)
 // centre look-ups are vector gathers served by L1/L2).  Works for any n.
 struct SceneGlobal {
     SceneView v;
+    static constexpr bool kHasNormTable = false;
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -232,6 +260,12 @@ struct SceneLds {
     SceneView v;
     const double* lgeom;  // LDS, 4 doubles per sphere
     const double* lmat;   // LDS, 8 doubles per sphere
+    const double* lnrm;   // LDS, 2 doubles per sphere: |hit - centre| as Magnitude returns it for a point
+                          // on the sphere, (double)sqrtf((float)(r*r)), and its refined reciprocal
+    static constexpr bool kHasNormTable = true;
+    __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 2]; }
+    __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 2 + 1]; }
+    __device__ __forceinline__ float norm_r2f(int id) const { return (float)lgeom[id * 4 + 3]; }
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -388,8 +422,14 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
     }
     const D3 hit_point = dir * dis + org;  // :79
     // D2: in literal mode the caller's normal stays (0,0,0); repaired: src/SettingData.cpp:214-215
-    const D3 normal =
-        (mode == RTM_MODE_LITERAL) ? d3(0, 0, 0) : normalize_i(m, hit_point - sc.center(id));
+    D3 normal = d3(0, 0, 0);
+    if (mode != RTM_MODE_LITERAL) {
+        const D3 dv = hit_point - sc.center(id);
+        if constexpr (Scene::kHasNormTable && std::is_same<MI, MathSpec>::value)
+            normal = m.normalize_on_sphere(dv, sc.norm_m(id), sc.norm_rinv(id), sc.norm_r2f(id));
+        else
+            normal = normalize_i(m, dv);
+    }
     // :82-83  w = Dot(n, d) < 0 ? n : n * -1.0  (multiplying by -1.0 flips the sign bit, exactly)
     const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));
     const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
