@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         park[5 * 64 + lane] = pdir.z;
     }
 
-    unsigned long long recq = 0;  // PACK8 records, most recent bounce in the low byte
+    unsigned long long recq = packed8_empty(P.scene.n);  // PACK8 records, most recent bounce in the low byte
     auto push = [&](int d, int id) {
         if constexpr (PACK8)
             recq = (recq << 8) | (unsigned long long)(unsigned)id;
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             else
                 dir = pdir;
             depth = 0;
+            if constexpr (PACK8) recq = packed8_empty(P.scene.n);
             rng = rng_open(pkey, n);
         }
         if constexpr (STAMP) {

@@ -555,26 +555,29 @@ __device__ __forceinline__ D3 path_fold_blocked(const Scene& sc, const D3 term, 
 template <class Scene>
 __device__ __forceinline__ D3 path_fold_packed8(const Scene& sc, const D3 term, const int depth,
                                                 const unsigned long long rec) {
+    // `rec` starts every path filled with the identity row's index, so bytes beyond `depth` already
+    // select the identity material: no per-level compare.
     D3 L = term;
-    const int identity = sc.n();
     const unsigned lo = (unsigned)rec, hi = (unsigned)(rec >> 32);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (g == 1 && __builtin_amdgcn_ballot_w64(depth > 4) == 0) break;
         const unsigned word = g ? hi : lo;
-        int id[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) id[k] = (g * 4 + k < depth) ? (int)((word >> (8 * k)) & 0xFFu) : identity;
         D3 c[4], e[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            c[k] = sc.color_kd(id[k]);
-            e[k] = sc.emission(id[k]);
+            const int id = (int)((word >> (8 * k)) & 0xFFu);
+            c[k] = sc.color_kd(id);
+            e[k] = sc.emission(id);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
     }
     return L;
+}
+// the 64-bit record register of a path that has not bounced yet: identity index in every byte
+__device__ __forceinline__ unsigned long long packed8_empty(int identity) {
+    return 0x0101010101010101ull * (unsigned long long)(unsigned)identity;
 }
 
 // src/Renderer.cpp:43-49: std::min<double>(std::max<double>(v, 0), 1.0f)
@@ -585,7 +588,12 @@ __device__ __forceinline__ double clamp01(double v) {
 // clampColor on a vec3.  The clamp is the identity unless a channel is < 0 or > 1 (NaN passes
 // through both comparisons unchanged), so the selects run only when some lane needs them.
 __device__ __forceinline__ D3 clamp01_d3(D3 c) {
-    const bool out = (c.x < 0.0) || (1.0 < c.x) || (c.y < 0.0) || (1.0 < c.y) || (c.z < 0.0) || (1.0 < c.z);
+    // v in [+0, 1] <=> its bit pattern, as an unsigned integer, is <= that of 1.0 (negative values,
+    // -0 and NaN have larger patterns and take the exact path below)
+    const unsigned long long one = 0x3FF0000000000000ull;
+    const bool out = ((unsigned long long)__double_as_longlong(c.x) > one) ||
+                     ((unsigned long long)__double_as_longlong(c.y) > one) ||
+                     ((unsigned long long)__double_as_longlong(c.z) > one);
     if (__builtin_amdgcn_ballot_w64(out) == 0) return c;
     return D3{clamp01(c.x), clamp01(c.y), clamp01(c.z)};
 }
