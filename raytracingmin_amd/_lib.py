@@ -83,7 +83,8 @@ SIGNATURES = {
     "rtm_write_jpg": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
 }
 # test hook (not in rtm.h)
-_EXTRA = {"rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p])}
+_EXTRA = {"rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+          "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)])}
 
 _lib = None
 

@@ -77,6 +77,9 @@ int rtm_debug_component_bench(int which, const rtm_sphere* sp, size_t n, int rep
     RTM_GUARD(rtm::component_bench(which, sp, n, reps, blocks, lds_pad, cycles_per_rep))
 }
 
+/* test hook: exhaustive device self-checks, returns the number of mismatches */
+int rtm_debug_selfcheck(int kind, unsigned long long* mismatches) { RTM_GUARD(rtm::selfcheck(kind, mismatches)) }
+
 int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,
                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
     RTM_GUARD(rtm::scene_load_json(path, literal_loader, settings, spheres, capacity, n_spheres))

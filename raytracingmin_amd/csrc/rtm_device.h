@@ -32,6 +32,22 @@ __device__ __forceinline__ double magnitude(D3 a) {
     const float len2 = (float)(a.x * a.x + a.y * a.y + a.z * a.z);
     return (double)__builtin_sqrtf(len2);
 }
+// The same float square root without hipcc's denormal pre-scaling and zero/inf fix-up: exact
+// (correctly rounded) for x in [2^-96, FLT_MAX]; callers flag anything else (sqrtf_fast_ok).
+// v_sqrt_f32 is within 1 ulp; the two fma residuals pick the neighbour when it is the rounded one —
+// the compiler's own correction step.  Checked against sqrtf for EVERY float in that range
+// (rtm_debug_selfcheck, tests/test_parity_gpu.py::test_fast_sqrtf_exhaustive).
+__device__ __forceinline__ bool sqrtf_fast_ok(float x) {
+    return (__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u);  // 2^-96 <= x < +inf
+}
+__device__ __forceinline__ float sqrtf_fast(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
 // src/Ray.h:70-72: three true divisions
 __device__ __forceinline__ D3 normalize(D3 a) { return a / magnitude(a); }
 

@@ -635,6 +635,25 @@ __global__ __launch_bounds__(64) void shade_bench_kernel(SceneView scene, D3 org
     if (lds_raw[0] == 77 && reps < 0) out[0] = 1;
 }
 
+// Exhaustive device-side self-checks (return the number of mismatching inputs).
+//   kind 0: sqrtf_fast == sqrtf for every float in [2^-96, FLT_MAX]
+__global__ void selfcheck_kernel(int kind, unsigned long long* mismatches) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    if (kind == 0) {
+        for (unsigned long long b = 0x0F800000ull + blockIdx.x * blockDim.x + threadIdx.x; b < 0x7F800000ull; b += stride) {
+            const float x = __uint_as_float((unsigned)b);
+            if (!sqrtf_fast_ok(x) || __float_as_uint(sqrtf_fast(x)) != __float_as_uint(__builtin_sqrtf(x))) ++bad;
+        }
+        // outside the range the guard must say so
+        const float outside[6] = {0.0f, -1.0f, 1e-30f, __uint_as_float(0x7F800000u), __uint_as_float(0x7FC00000u), 1e-38f};
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int i = 0; i < 6; ++i)
+                if (sqrtf_fast_ok(outside[i])) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // Device primitives exposed for parity tests of the building blocks (tests/test_device_math.py).
 __global__ void math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
                                   size_t n, double* __restrict__ out) {
@@ -715,10 +734,10 @@ static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& g
         mat[i * 8 + 0] = sp[i].color[0] / kd;
         mat[i * 8 + 1] = sp[i].color[1] / kd;
         mat[i * 8 + 2] = sp[i].color[2] / kd;
-        mat[i * 8 + 3] = kd;
-        mat[i * 8 + 4] = sp[i].emission[0];
-        mat[i * 8 + 5] = sp[i].emission[1];
-        mat[i * 8 + 6] = sp[i].emission[2];
+        mat[i * 8 + 3] = sp[i].emission[0];
+        mat[i * 8 + 4] = sp[i].emission[1];
+        mat[i * 8 + 5] = sp[i].emission[2];
+        mat[i * 8 + 6] = kd;
         mat[i * 8 + 7] = 0.0;
     }
 }
@@ -742,10 +761,10 @@ __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n
     mat[i * 8 + 0] = sp[i].color[0] / kd;
     mat[i * 8 + 1] = sp[i].color[1] / kd;
     mat[i * 8 + 2] = sp[i].color[2] / kd;
-    mat[i * 8 + 3] = kd;
-    mat[i * 8 + 4] = sp[i].emission[0];
-    mat[i * 8 + 5] = sp[i].emission[1];
-    mat[i * 8 + 6] = sp[i].emission[2];
+    mat[i * 8 + 3] = sp[i].emission[0];
+    mat[i * 8 + 4] = sp[i].emission[1];
+    mat[i * 8 + 5] = sp[i].emission[2];
+    mat[i * 8 + 6] = kd;
     mat[i * 8 + 7] = 0.0;
 }
 
@@ -1233,6 +1252,18 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
     *cycles_per_rep = sum / blocks / reps;
     (void)hipFree(out);
     (void)hipFree(cyc);
+    return RTM_OK;
+}
+
+int selfcheck(int kind, unsigned long long* mismatches) {
+    if (!mismatches) return RTM_ERR_INVALID_ARGUMENT;
+    unsigned long long* d;
+    RTM_HIP_CHECK(hipMalloc((void**)&d, 8));
+    RTM_HIP_CHECK(hipMemset(d, 0, 8));
+    selfcheck_kernel<<<4096, 256>>>(kind, d);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
     return RTM_OK;
 }
 

@@ -149,6 +149,33 @@ struct MathSpec {
         else
             sincos_small(x, sn, cs);
     }
+    // Magnitude (src/Ray.h:67-69) with the unscaled float sqrt
+    __device__ __forceinline__ double magnitude_spec(D3 a) {
+        const float len2 = (float)(a.x * a.x + a.y * a.y + a.z * a.z);
+        bad = bad || !sqrtf_fast_ok(len2);
+        return (double)sqrtf_fast(len2);
+    }
+    __device__ __forceinline__ D3 normalize(D3 a) { return div3(a, magnitude_spec(a)); }
+    // Normalize of a vector whose y component is a (signed) zero — Cross((0,1,0), w) for finite w:
+    // y*y adds +0 to the squared length and +-0 / m is the same +-0, so only x and z are divided.
+    // Anything else in y (NaN from a non-finite w) trips `bad`.
+    __device__ __forceinline__ D3 normalize_y0(D3 a) {
+        const float len2 = (float)(a.x * a.x + a.z * a.z);
+        bad = bad || !sqrtf_fast_ok(len2) || !(a.y == 0.0);
+        const double y = (double)sqrtf_fast(len2);
+        bad = bad || !(MathFast::moderate(a.x) && MathFast::moderate(a.z));  // y: a normal float here
+        double r = __builtin_amdgcn_rcp(y);
+        double e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        auto one = [&](double x) {
+            const double q = x * r;
+            const double rem = __builtin_fma(-y, q, x);
+            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+        };
+        return D3{one(a.x), a.y, one(a.z)};
+    }
     // Normalize(hit - centre) (src/SettingData.cpp:214-215) for a hit point that is ON its sphere to
     // float precision: then (float)|dv|^2 is exactly (float)(r*r), so Magnitude returns the
     // per-sphere constant `ms` and the reciprocal refinement of the three divisions is the
@@ -157,7 +184,10 @@ struct MathSpec {
     __device__ __forceinline__ D3 normalize_on_sphere(D3 dv, double ms, double rinv, float r2f) {
         const float len2f = (float)(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
         const bool canon = (len2f == r2f) && (rinv == rinv);
-        if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3(dv, (double)__builtin_sqrtf(len2f));
+        if (__builtin_amdgcn_ballot_w64(!canon) != 0) {
+            bad = bad || !sqrtf_fast_ok(len2f);
+            return div3(dv, (double)sqrtf_fast(len2f));
+        }
         bad = bad || !(MathFast::moderate(dv.x) && MathFast::moderate(dv.y) && MathFast::moderate(dv.z));
         auto one = [&](double x) {
             const double q = x * rinv;
@@ -181,6 +211,8 @@ __device__ __forceinline__ double refined_rcp_or_nan(double y) {
 struct MathRefI {
     static constexpr bool bad = false;
     const double* trig_lds = nullptr;
+    __device__ __forceinline__ D3 normalize(D3 a) { return MathRef::div3(a, magnitude(a)); }
+    __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathRef::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathRef::div3(a, y); }
     // r1 = 2*pi*u < 2^30 always: ocml's small-argument sequence IS ::sincos there (bit-identical)
@@ -193,6 +225,8 @@ struct MathRefI {
 };
 struct MathFastI {
     static constexpr bool bad = false;
+    __device__ __forceinline__ D3 normalize(D3 a) { return MathFast::div3(a, magnitude(a)); }
+    __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathFast::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathFast::div3(a, y); }
     __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
@@ -205,12 +239,12 @@ __device__ __forceinline__ D3 normalize_m(D3 a) {
 }
 template <class MI>
 __device__ __forceinline__ D3 normalize_i(MI& m, D3 a) {
-    return m.div3(a, magnitude(a));
+    return m.normalize(a);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Scene policies.  geom[i] = (cx, cy, cz, (double)(float)(r*r)); mat[i*8..] = colorKD.xyz, kd,
-// emission.xyz, pad.
+// Scene policies.  geom[i] = (cx, cy, cz, (double)(float)(r*r)); mat[i*8..] = colorKD.xyz,
+// emission.xyz, kd, pad (the fold reads the first six doubles of a row as three 16-byte loads).
 // ------------------------------------------------------------------------------------------------
 struct SceneView {
     const double4* __restrict__ geom;
@@ -243,10 +277,10 @@ struct SceneGlobal {
         const double4 g = v.geom[id];
         return D3{g.x, g.y, g.z};
     }
-    __device__ __forceinline__ double kd(int id) const { return v.mat[(size_t)id * 8 + 3]; }
+    __device__ __forceinline__ double kd(int id) const { return v.mat[(size_t)id * 8 + 6]; }
     __device__ __forceinline__ D3 emission(int id) const {
         const double* m = v.mat + (size_t)id * 8;
-        return D3{m[4], m[5], m[6]};
+        return D3{m[3], m[4], m[5]};
     }
     __device__ __forceinline__ D3 color_kd(int id) const {
         const double* m = v.mat + (size_t)id * 8;
@@ -272,10 +306,10 @@ struct SceneLds {
         const double* g = lgeom + id * 4;
         return D3{g[0], g[1], g[2]};
     }
-    __device__ __forceinline__ double kd(int id) const { return lmat[id * 8 + 3]; }
+    __device__ __forceinline__ double kd(int id) const { return lmat[id * 8 + 6]; }
     __device__ __forceinline__ D3 emission(int id) const {
         const double* m = lmat + id * 8;
-        return D3{m[4], m[5], m[6]};
+        return D3{m[3], m[4], m[5]};
     }
     __device__ __forceinline__ D3 color_kd(int id) const {
         const double* m = lmat + id * 8;
@@ -440,11 +474,14 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
     // :96-101 — one Normalize on the selected cross product (same values as the two-armed if)
     const bool use_y = fabs(w.x) > (double)FLT_MIN;
     D3 c = cross(d3(0, 1, 0), w);
+    D3 u;
     if (__builtin_amdgcn_ballot_w64(!use_y) != 0) {  // some lane has |w.x| <= FLT_MIN (e.g. literal mode)
         const D3 cx = cross(d3(1, 0, 0), w);
         c = d3(use_y ? c.x : cx.x, use_y ? c.y : cx.y, use_y ? c.z : cx.z);
+        u = normalize_i(m, c);
+    } else {
+        u = m.normalize_y0(c);  // c.y = (-0)*w.z + 0*w.x is a signed zero for finite w
     }
-    const D3 u = normalize_i(m, c);
     const D3 v = cross(w, u);  // :102
     double sn, cs;
     m.sincos_r1(r1, sn, cs);

@@ -117,6 +117,14 @@ def test_sincos_small_matches_ocml(rtm):
     assert np.array_equal(_probe(rtm, 13, x).view(np.uint64), _probe(rtm, 6, x).view(np.uint64))
 
 
+def test_fast_sqrtf_exhaustive(rtm):
+    """The unscaled float sqrt of the shading block equals sqrtf for EVERY float in [2^-96, FLT_MAX]
+    (1.9e9 values, checked on the device) and its guard rejects everything outside."""
+    bad = C.c_uint64(123)
+    rtm._lib.check(rtm.lib().rtm_debug_selfcheck(0, C.byref(bad)), "selfcheck")
+    assert bad.value == 0
+
+
 def test_speculative_math_is_bit_identical(rtm):
     """MathSpec + its validity flag (falls back when set) == compiler math, all operand classes."""
     rng = np.random.default_rng(5)
