@@ -92,6 +92,9 @@ def main():
                          "c5 100k-sphere stress scene 1080p x 256spp (use --rows to bound it)")
     ap.add_argument("--rows", default="", help="render only rows a:b of the frame (value counts those samples)")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + --same-device rehearses the N-rank path on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -106,11 +109,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
                super_samples=args.super_samples, max_bounces=args.max_bounces)
@@ -178,7 +186,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])

@@ -32,6 +32,8 @@ def gather_strips(local, strips, rank, world, dst=0, group=None):
     elsewhere."""
     import torch
     import torch.distributed as dist
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # gloo rehearsal of the N-rank path: host tensors
     max_rows = max(e - b for b, e in strips)
     rows = strips[rank][1] - strips[rank][0]
     if rows == max_rows:
