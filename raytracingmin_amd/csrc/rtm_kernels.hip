@@ -480,6 +480,10 @@ __global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderPar
     }
 }
 
+}  // namespace rtm
+#include "rtm_wavefront.h"
+namespace rtm {
+
 // ------------------------------------------------------------------------------------------------
 // Per-ray seam: png::PathTracing for a batch of rays (one lane per ray).
 struct RayBatchParams {
@@ -844,9 +848,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8-park-pack8",
                                       "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
                                       "fast-math-lds-tables-chunk8-nopark-pack8", "fast-math-lds-tables-chunk8-park-ldsrecords",
-                                      "diagnostic-stamped (segment cycle shares, not for timing)"};
+                                      "diagnostic-stamped (segment cycle shares, not for timing)",
+                                      "wavefront-lds-scene-tiles"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4;
+              kVariantSceneTiled = 4, kVariantWavefront = 8;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -961,6 +966,78 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     }
 }
 
+// Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
+// the compacted active list is empty.  Synchronous: the list length is read back every iteration.
+static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
+    constexpr int TILE = 512, K = 4;
+    WfState S;
+    std::memset(&S, 0, sizeof S);
+    S.npix = (unsigned)rows * (unsigned)P.W;
+    // record levels per pixel: the cap when there is one, else as many as 2 GiB of HBM buy
+    // (64..1024); a deeper path fails loudly like in the other variants
+    if (P.max_bounces >= 0 && P.max_bounces <= 1024) {
+        S.levels = P.max_bounces > 0 ? P.max_bounces : 1;
+    } else {
+        const size_t budget = ((size_t)2 << 30) / (4 * (size_t)S.npix);
+        S.levels = (int)(budget < 64 ? 64 : (budget > 1024 ? 1024 : budget));
+    }
+    const size_t N = S.npix;
+    const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256;
+    unsigned char* ws = nullptr;
+    RTM_HIP_CHECK(hipMallocAsync((void**)&ws, bytes, stream));
+    struct Free {
+        void* p;
+        hipStream_t s;
+        ~Free() { (void)hipFreeAsync(p, s); }
+    } free_ws{ws, stream};
+    unsigned char* q = ws;
+    auto take = [&](size_t b) {
+        unsigned char* r = q;
+        q += (b + 15) & ~(size_t)15;
+        return r;
+    };
+    S.org = (double*)take(N * 24);
+    S.dir = (double*)take(N * 24);
+    S.pdir = (double*)take(N * 24);
+    S.acc = (double*)take(N * 24);
+    S.hit_t = (double*)take(N * 8);
+    S.hit_id = (int*)take(N * 4);
+    S.rng_ctr = (unsigned*)take(N * 4);
+    S.rng_k1 = (unsigned*)take(N * 4);
+    S.n = (unsigned*)take(N * 4);
+    S.left = (int*)take(N * 4);
+    S.depth = (int*)take(N * 4);
+    S.rec = (unsigned*)take(N * 4 * (size_t)S.levels);
+    S.active[0] = (unsigned*)take(N * 4);
+    S.active[1] = (unsigned*)take(N * 4);
+    S.n_active = (unsigned*)take(16);
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    const unsigned init_counts[2] = {S.npix, 0u};
+    RTM_HIP_CHECK(hipMemcpyAsync(S.n_active, init_counts, sizeof init_counts, hipMemcpyHostToDevice, stream));
+    wf_init_kernel<<<grid, 256, 0, stream>>>(P, S);
+    RTM_HIP_CHECK(hipGetLastError());
+    const size_t lds = 2 * (size_t)TILE * 32;
+    unsigned na = S.npix;
+    int cur = 0;
+    // every cast of every pixel is one trip; a pixel needs at most total_samples * (depth cap + 1)
+    const unsigned long long max_trips = (unsigned long long)P.total_samples * (unsigned long long)(S.levels + 1) + 8;
+    for (unsigned long long trip = 0; na > 0; ++trip) {
+        if (trip > max_trips) {
+            set_last_error("wavefront loop did not terminate");
+            return RTM_ERR_HIP;
+        }
+        const unsigned g = (na + 255) / 256;
+        RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
+        wf_nearest_kernel<MathFast, TILE, K><<<g, 256, lds, stream>>>(P, S, cur);
+        wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
+        RTM_HIP_CHECK(hipGetLastError());
+        RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + (cur ^ 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        cur ^= 1;
+    }
+    return RTM_OK;
+}
+
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
                   const rtm_options* opt, double* out64, float* out32, uint8_t* out8,
                   void* stream_v, rtm_stats* stats) {
@@ -1017,7 +1094,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventCreate(&ev1));
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
-    launch_render(opt->variant, P, grid, tiles_y, stream);
+    if (opt->variant == kVariantWavefront) {
+        rc = run_wavefront(P, rows, stream);
+        if (rc != RTM_OK) return rc;
+    } else {
+        launch_render(opt->variant, P, grid, tiles_y, stream);
+    }
     RTM_HIP_CHECK(hipGetLastError());
     if (stamps) {  // diagnostic variant: print the per-wave segment shares
         RTM_HIP_CHECK(hipStreamSynchronize(stream));

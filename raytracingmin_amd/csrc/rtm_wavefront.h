@@ -1,0 +1,225 @@
+// rtm_wavefront.h — large scenes (BASELINE configs[4], 100 k spheres) as a wavefront pipeline.
+// Included by rtm_kernels.hip after RenderParams / primary_dir / store_pixel / wave_add_counter.
+//
+// With 10^5 spheres a ray cast is ~2 M instructions of brute-force intersection against ~500 of
+// shading, so the two are split into kernels with their own register budgets:
+//   wf_nearest  one lane per ACTIVE pixel (compacted index list), nothing live but the ray and the
+//               running nearest hit: few VGPRs, many waves per SIMD.  The sphere list is streamed
+//               HBM/L2 -> LDS in tiles by the whole workgroup (coalesced 16-byte loads, double
+//               buffered through registers); all lanes read the same LDS address per sphere; a chunk
+//               of spheres the whole wave misses costs 17 flops + one compare per sphere.
+//   wf_shade    the rest of PathTracing (src/Renderer.cpp:75-117), the back-to-front fold, the
+//               per-sample accumulate and path regeneration, with the per-pixel state in HBM (SoA),
+//               then wave-ballot/prefix COMPACTION of the pixels that still have samples into the
+//               next active list.
+// One path per pixel at a time and samples in the reference's order, so every pixel sees exactly the
+// arithmetic of render_tiles_kernel: the image is bit-identical to the other variants.
+// Per-pixel state traffic (~300 B read + written per cast) is noise next to the intersection work.
+#pragma once
+
+namespace rtm {
+
+struct WfState {
+    double* org;    // [3][npix]
+    double* dir;    // [3][npix]
+    double* pdir;   // [3][npix] cached primary direction of the current sub-pixel
+    double* acc;    // [3][npix]
+    double* hit_t;  // [npix]
+    int* hit_id;    // [npix]
+    unsigned* rng_ctr;
+    unsigned* rng_k1;
+    unsigned* n;     // sample index
+    int* left;       // samples left in the current sub-pixel
+    int* depth;
+    unsigned* rec;   // [levels][npix] hit records
+    unsigned* active[2];
+    unsigned* n_active;  // [2]
+    unsigned npix;
+    int levels;
+};
+
+__device__ __forceinline__ void wf_pixel_xy(const RenderParams& P, unsigned p, int& x, int& y) {
+    x = (int)(p % (unsigned)P.W);
+    y = P.row_begin + (int)(p / (unsigned)P.W);
+}
+
+__global__ __launch_bounds__(256) void wf_init_kernel(const RenderParams P, const WfState S) {
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= S.npix) return;
+    int x, y;
+    wf_pixel_xy(P, p, x, y);
+    const D3 pd = primary_dir(P, x, y, 1, 1);
+    const unsigned N = S.npix;
+    S.org[p] = P.cam_org.x; S.org[N + p] = P.cam_org.y; S.org[2 * N + p] = P.cam_org.z;
+    S.dir[p] = pd.x; S.dir[N + p] = pd.y; S.dir[2 * N + p] = pd.z;
+    S.pdir[p] = pd.x; S.pdir[N + p] = pd.y; S.pdir[2 * N + p] = pd.z;
+    S.acc[p] = 0.0; S.acc[N + p] = 0.0; S.acc[2 * N + p] = 0.0;
+    const RngStream r = rng_open(rng_pixel_key(P.seed_mult, (uint32_t)y * (uint32_t)P.W + (uint32_t)x), 0u);
+    S.rng_ctr[p] = r.ctr;
+    S.rng_k1[p] = r.k1;
+    S.n[p] = 0;
+    S.left[p] = P.S;
+    S.depth[p] = 0;
+    S.active[0][p] = p;
+}
+
+// Nearest hit for the active pixels (src/Renderer.cpp:58-73 + src/SettingData.cpp:197-226).
+template <class M, int TILE, int K>
+__global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, const WfState S, const int cur) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double2* tile_buf = reinterpret_cast<double2*>(lds_raw);  // 2 x TILE x 2 double2
+    const unsigned na = S.n_active[cur];
+    if (blockIdx.x * 256u >= na) return;  // whole block beyond the active list
+    const int tid = threadIdx.x;
+    const unsigned i = blockIdx.x * 256u + tid;
+    const bool live = i < na;
+    const unsigned p = S.active[cur][live ? i : na - 1];
+    const unsigned N = S.npix;
+    const D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
+    const D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
+
+    constexpr int CHUNKS = TILE * 2 / 256;
+    const int n = P.scene.n;
+    const int n_tiles = (n + TILE - 1) / TILE;
+    const double2* gsrc = reinterpret_cast<const double2*>(P.scene.geom);
+    const int n_chunks = n * 2;
+    double dis = DBL_MAX;
+    int id = -1;
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+        const int c = k * 256 + tid;
+        tile_buf[c] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
+    }
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        double2 pre[CHUNKS];
+        const bool more = (t + 1 < n_tiles);
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) {
+                const int c = (t + 1) * TILE * 2 + k * 256 + tid;
+                pre[k] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
+            }
+        }
+        const int base = t * TILE;
+        const int cnt = (n - base < TILE) ? (n - base) : TILE;
+        struct TileGeom {
+            const double2* cur;
+            int base;
+            __device__ __forceinline__ double4 geom_uniform(int i) const {
+                const double2 a = cur[2 * (i - base)], b = cur[2 * (i - base) + 1];
+                return double4{a.x, a.y, b.x, b.y};
+            }
+        } tile{tile_buf + (t & 1) * TILE * 2, base};
+        int j = 0;
+        for (; j + K <= cnt; j += K) sphere_chunk<M, K, TileGeom, true>(tile, base + j, org, dir, dis, id);
+        for (; j < cnt; ++j) sphere_chunk<M, 1, TileGeom, true>(tile, base + j, org, dir, dis, id);
+        if (more) {
+            double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
+#pragma unroll
+            for (int k = 0; k < CHUNKS; ++k) nxt[k * 256 + tid] = pre[k];
+        }
+        __syncthreads();
+    }
+    if (live) {
+        S.hit_id[p] = id;
+        S.hit_t[p] = dis;
+    }
+}
+
+// Shade / fold / accumulate / regenerate for the active pixels, then compaction of the survivors.
+__global__ __launch_bounds__(256) void wf_shade_kernel(const RenderParams P, const WfState S, const int cur) {
+    const unsigned na = S.n_active[cur];
+    if (blockIdx.x * 256u >= na) return;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < na;
+    const unsigned N = S.npix;
+    PathCounters pc = {0, 0, 0};
+    bool overflow = false;
+    bool alive = false;
+    unsigned p = 0;
+    if (live) {
+        p = S.active[cur][i];
+        SceneGlobal sc;
+        sc.v = P.scene;
+        D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
+        D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
+        RngStream rng{S.rng_ctr[p], S.rng_k1[p]};
+        int depth = S.depth[p];
+        unsigned n = S.n[p];
+        auto push = [&](int d, int id) {
+            if (d < S.levels)
+                S.rec[(size_t)d * N + p] = (unsigned)id;
+            else
+                overflow = true;
+        };
+        D3 term;
+        bool cont = path_shade_spec(sc, S.hit_id[p], S.hit_t[p], P.mode, P.max_bounces, org, dir, depth, rng, term,
+                                    pc, push);
+        if (cont && overflow) {
+            cont = false;
+            term = d3(0, 0, 0);
+            depth = 0;
+        }
+        if (!cont) {
+            const D3 L = path_fold(sc, term, depth, [&](int d) { return (int)S.rec[(size_t)d * N + p]; });
+            const bool pow2 = P.inv_s != 0.0;
+            const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
+            const D3 add = clamp01_d3(cal);
+            const D3 acc = d3(S.acc[p], S.acc[N + p], S.acc[2 * N + p]) + add;
+            S.acc[p] = acc.x; S.acc[N + p] = acc.y; S.acc[2 * N + p] = acc.z;
+            ++n;
+            int left = S.left[p] - 1;
+            int x, y;
+            wf_pixel_xy(P, p, x, y);
+            if (n < P.total_samples) {
+                D3 pd;
+                if (left == 0) {
+                    left = P.S;
+                    const int sub = (int)(n / (unsigned)P.S);
+                    pd = primary_dir(P, x, y, sub / P.SS + 1, sub % P.SS + 1);
+                    S.pdir[p] = pd.x; S.pdir[N + p] = pd.y; S.pdir[2 * N + p] = pd.z;
+                } else {
+                    pd = d3(S.pdir[p], S.pdir[N + p], S.pdir[2 * N + p]);
+                }
+                org = P.cam_org;
+                dir = pd;
+                depth = 0;
+                rng = rng_open(rng_pixel_key(P.seed_mult, (uint32_t)y * (uint32_t)P.W + (uint32_t)x), n);
+            } else {
+                store_pixel(P, true, x, y, acc);
+            }
+            S.left[p] = left;
+            S.n[p] = n;
+        }
+        alive = n < P.total_samples;
+        if (alive) {
+            S.org[p] = org.x; S.org[N + p] = org.y; S.org[2 * N + p] = org.z;
+            S.dir[p] = dir.x; S.dir[N + p] = dir.y; S.dir[2 * N + p] = dir.z;
+            S.rng_ctr[p] = rng.ctr;
+            S.rng_k1[p] = rng.k1;
+            S.depth[p] = depth;
+        }
+    }
+    // ---- compaction: wave ballot + prefix, one atomic per wave ----
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(alive);
+    if (mask) {
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned count = (unsigned)__builtin_popcountll(mask);
+        unsigned base = 0;
+        if (lane == (unsigned)__builtin_ctzll(mask)) base = atomicAdd(&S.n_active[cur ^ 1], count);
+        base = (unsigned)__shfl((int)base, (int)__builtin_ctzll(mask), 64);
+        if (alive) {
+            const unsigned before = (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            S.active[cur ^ 1][base + before] = p;
+        }
+    }
+    if (P.counters) {
+        wave_add_counter(P.counters + 0, pc.casts);
+        wave_add_counter(P.counters + 1, pc.bounces);
+        wave_add_counter(P.counters + 2, pc.draws);
+        if (overflow) atomicOr(P.counters + 3, 1ull);
+    }
+}
+
+}  // namespace rtm
