@@ -968,8 +968,16 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
 // the compacted active list is empty.  Synchronous: the list length is read back every iteration.
+template <int TILE, int K>
+static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, unsigned g, hipStream_t stream) {
+    wf_nearest_kernel<MathFast, TILE, K><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
+}
+
 static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
-    constexpr int TILE = 512, K = 4;
+    static const int cfg = [] {  // tuning knob (profiles/): RTM_WF_CONFIG=0..4
+        const char* e = std::getenv("RTM_WF_CONFIG");
+        return e ? std::atoi(e) : 0;
+    }();
     WfState S;
     std::memset(&S, 0, sizeof S);
     S.npix = (unsigned)rows * (unsigned)P.W;
@@ -1016,7 +1024,6 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
     RTM_HIP_CHECK(hipMemcpyAsync(S.n_active, init_counts, sizeof init_counts, hipMemcpyHostToDevice, stream));
     wf_init_kernel<<<grid, 256, 0, stream>>>(P, S);
     RTM_HIP_CHECK(hipGetLastError());
-    const size_t lds = 2 * (size_t)TILE * 32;
     unsigned na = S.npix;
     int cur = 0;
     // every cast of every pixel is one trip; a pixel needs at most total_samples * (depth cap + 1)
@@ -1028,7 +1035,13 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
         }
         const unsigned g = (na + 255) / 256;
         RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-        wf_nearest_kernel<MathFast, TILE, K><<<g, 256, lds, stream>>>(P, S, cur);
+        switch (cfg) {
+            case 1: launch_wf_nearest<512, 2>(P, S, cur, g, stream); break;
+            case 2: launch_wf_nearest<256, 2>(P, S, cur, g, stream); break;
+            case 3: launch_wf_nearest<256, 4>(P, S, cur, g, stream); break;
+            case 4: launch_wf_nearest<1024, 2>(P, S, cur, g, stream); break;
+            default: launch_wf_nearest<512, 4>(P, S, cur, g, stream); break;
+        }
         wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
         RTM_HIP_CHECK(hipGetLastError());
         RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + (cur ^ 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1094,7 +1107,10 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventCreate(&ev1));
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
-    if (opt->variant == kVariantWavefront) {
+    // auto: scenes beyond the LDS-table size go through the wavefront pipeline
+    const bool wavefront = opt->variant == kVariantWavefront ||
+                           (opt->variant == kVariantAuto && n > (size_t)kLdsTableMaxSpheres);
+    if (wavefront) {
         rc = run_wavefront(P, rows, stream);
         if (rc != RTM_OK) return rc;
     } else {
