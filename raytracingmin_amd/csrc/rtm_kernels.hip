@@ -968,16 +968,15 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
 // the compacted active list is empty.  Synchronous: the list length is read back every iteration.
-template <int TILE, int K>
-static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, unsigned g, hipStream_t stream) {
-    wf_nearest_kernel<MathFast, TILE, K><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
+template <int TILE, int K, int R>
+static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, unsigned na, hipStream_t stream) {
+    const unsigned g = (na + 256 * R - 1) / (256 * R);
+    wf_nearest_kernel<MathFast, TILE, K, R><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
 }
 
 static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
-    static const int cfg = [] {  // tuning knob (profiles/): RTM_WF_CONFIG=0..4
-        const char* e = std::getenv("RTM_WF_CONFIG");
-        return e ? std::atoi(e) : 0;
-    }();
+    // (TILE, K, R) = (512 spheres per LDS tile, 4 per chunk, 1 ray per lane): profiles/r1/wf_tune.txt —
+    // smaller chunks or 2-4 rays per lane (fewer LDS reads per ray, fewer waves) were 0-50 % slower
     WfState S;
     std::memset(&S, 0, sizeof S);
     S.npix = (unsigned)rows * (unsigned)P.W;
@@ -1035,13 +1034,7 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
         }
         const unsigned g = (na + 255) / 256;
         RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-        switch (cfg) {
-            case 1: launch_wf_nearest<512, 2>(P, S, cur, g, stream); break;
-            case 2: launch_wf_nearest<256, 2>(P, S, cur, g, stream); break;
-            case 3: launch_wf_nearest<256, 4>(P, S, cur, g, stream); break;
-            case 4: launch_wf_nearest<1024, 2>(P, S, cur, g, stream); break;
-            default: launch_wf_nearest<512, 4>(P, S, cur, g, stream); break;
-        }
+        launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
         wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
         RTM_HIP_CHECK(hipGetLastError());
         RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + (cur ^ 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));

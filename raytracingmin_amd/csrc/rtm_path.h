@@ -364,16 +364,15 @@ __device__ __forceinline__ void sphere_update(const double4 g, const D3 org, con
 // profiles/ubench/nearest_variants.hip: 36 % fewer cycles per cast than the per-sphere loop.
 // EARLY_OUT (scenes of many small spheres): when no lane of the wave has D4 >= 0 for any sphere of
 // the chunk — the common case there — the square roots and updates are skipped altogether.
-template <class M, int K, class Scene, bool EARLY_OUT = false>
-__device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
-                                             double& dis, int& hit_object) {
+template <class M, int K, bool EARLY_OUT = false>
+__device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int i0, const D3 org, const D3 dir,
+                                               double& dis, int& hit_object) {
     double b[K], D4[K], sq[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const double4 g = sc.geom_uniform(i0 + k);
-        const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
-        b[k] = dot(p_o, dir);                                      // :199
-        D4[k] = b[k] * b[k] - dot(p_o, p_o) + g.w;                 // :200
+        const D3 p_o = d3(g[k].x - org.x, g[k].y - org.y, g[k].z - org.z);  // src/SettingData.cpp:198
+        b[k] = dot(p_o, dir);                                               // :199
+        D4[k] = b[k] * b[k] - dot(p_o, p_o) + g[k].w;                       // :200
     }
     if constexpr (EARLY_OUT) {
         bool any = false;  // a NaN discriminant (literal mode) is "not >= 0": it can never be accepted
@@ -390,6 +389,14 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
         dis = accept ? t : dis;
         hit_object = accept ? i0 + k : hit_object;
     }
+}
+template <class M, int K, class Scene, bool EARLY_OUT = false>
+__device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
+                                             double& dis, int& hit_object) {
+    double4 g[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[k] = sc.geom_uniform(i0 + k);
+    sphere_chunk_g<M, K, EARLY_OUT>(g, i0, org, dir, dis, hit_object);
 }
 
 // src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.

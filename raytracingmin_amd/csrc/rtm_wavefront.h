@@ -64,27 +64,37 @@ __global__ __launch_bounds__(256) void wf_init_kernel(const RenderParams P, cons
 }
 
 // Nearest hit for the active pixels (src/Renderer.cpp:58-73 + src/SettingData.cpp:197-226).
-template <class M, int TILE, int K>
+// R rays per lane: the geometry of a chunk is read from LDS once and tested against R rays, which
+// divides the broadcast LDS reads per ray by R.
+template <class M, int TILE, int K, int R>
 __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, const WfState S, const int cur) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double2* tile_buf = reinterpret_cast<double2*>(lds_raw);  // 2 x TILE x 2 double2
     const unsigned na = S.n_active[cur];
-    if (blockIdx.x * 256u >= na) return;  // whole block beyond the active list
+    if (blockIdx.x * (256u * R) >= na) return;  // whole block beyond the active list
     const int tid = threadIdx.x;
-    const unsigned i = blockIdx.x * 256u + tid;
-    const bool live = i < na;
-    const unsigned p = S.active[cur][live ? i : na - 1];
     const unsigned N = S.npix;
-    const D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
-    const D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
+    unsigned p[R];
+    bool live[R];
+    D3 org[R], dir[R];
+    double dis[R];
+    int id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned i = blockIdx.x * (256u * R) + r * 256u + tid;
+        live[r] = i < na;
+        p[r] = S.active[cur][live[r] ? i : na - 1];
+        org[r] = d3(S.org[p[r]], S.org[N + p[r]], S.org[2 * N + p[r]]);
+        dir[r] = d3(S.dir[p[r]], S.dir[N + p[r]], S.dir[2 * N + p[r]]);
+        dis[r] = DBL_MAX;
+        id[r] = -1;
+    }
 
     constexpr int CHUNKS = TILE * 2 / 256;
     const int n = P.scene.n;
     const int n_tiles = (n + TILE - 1) / TILE;
     const double2* gsrc = reinterpret_cast<const double2*>(P.scene.geom);
     const int n_chunks = n * 2;
-    double dis = DBL_MAX;
-    int id = -1;
 #pragma unroll
     for (int k = 0; k < CHUNKS; ++k) {
         const int c = k * 256 + tid;
@@ -103,17 +113,25 @@ __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, c
         }
         const int base = t * TILE;
         const int cnt = (n - base < TILE) ? (n - base) : TILE;
-        struct TileGeom {
-            const double2* cur;
-            int base;
-            __device__ __forceinline__ double4 geom_uniform(int i) const {
-                const double2 a = cur[2 * (i - base)], b = cur[2 * (i - base) + 1];
-                return double4{a.x, a.y, b.x, b.y};
-            }
-        } tile{tile_buf + (t & 1) * TILE * 2, base};
+        const double2* curt = tile_buf + (t & 1) * TILE * 2;
         int j = 0;
-        for (; j + K <= cnt; j += K) sphere_chunk<M, K, TileGeom, true>(tile, base + j, org, dir, dis, id);
-        for (; j < cnt; ++j) sphere_chunk<M, 1, TileGeom, true>(tile, base + j, org, dir, dis, id);
+        for (; j + K <= cnt; j += K) {
+            double4 g[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {  // same LDS address in every lane: broadcast
+                const double2 a = curt[2 * (j + k)], b = curt[2 * (j + k) + 1];
+                g[k] = double4{a.x, a.y, b.x, b.y};
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) sphere_chunk_g<M, K, true>(g, base + j, org[r], dir[r], dis[r], id[r]);
+        }
+        for (; j < cnt; ++j) {
+            double4 g[1];
+            const double2 a = curt[2 * j], b = curt[2 * j + 1];
+            g[0] = double4{a.x, a.y, b.x, b.y};
+#pragma unroll
+            for (int r = 0; r < R; ++r) sphere_chunk_g<M, 1, true>(g, base + j, org[r], dir[r], dis[r], id[r]);
+        }
         if (more) {
             double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
 #pragma unroll
@@ -121,10 +139,12 @@ __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, c
         }
         __syncthreads();
     }
-    if (live) {
-        S.hit_id[p] = id;
-        S.hit_t[p] = dis;
-    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (live[r]) {
+            S.hit_id[p[r]] = id[r];
+            S.hit_t[p[r]] = dis[r];
+        }
 }
 
 // Shade / fold / accumulate / regenerate for the active pixels, then compaction of the survivors.
