@@ -225,7 +225,8 @@ def main():
                                    f"{spp}spp (SS {cfg['super_samples']} x S {cfg['samples']}), L1 repaired, "
                                    f"max_bounces {cfg['max_bounces']}, seed 0x5EED, row strips over "
                                    f"{world} GPU(s) + one gather",
-                       "variant": rtm.lib().rtm_variant_name(args.variant).decode(),
+                       "variant": rtm.lib().rtm_variant_name(
+                           args.variant if args.variant else (2 if n_spheres <= 256 else 8)).decode(),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
