@@ -12,6 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "raytracingmin_amd", "rtm_cli")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built_cli():
+    if not os.path.exists(CLI):  # a tree without build artefacts: build them (hipcc is in the image)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "raytracingmin_amd", "csrc")],
+                              stdout=subprocess.DEVNULL)
+    assert os.path.exists(CLI)
+
+
 def test_cli_renders_shipped_scene_and_writes_both_files(tmp_path, oracle):
     from PIL import Image
     scene = oracle.scene_path("cornellBoxSetting.json")
