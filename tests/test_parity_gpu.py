@@ -400,9 +400,9 @@ def test_empty_scene_and_device_errors(rtm, oracle):
 
 
 def test_headline_config_strip_vs_oracle(rtm, oracle):
-    """BASELINE configs[2] (1920x1080, 1024 spp, max 8 bounces) rendered in full on the GPU; two
-    full-width rows are checked against the oracle at the full 1024 spp, plus size-independent
-    properties of the whole frame."""
+    """BASELINE configs[2] (1920x1080, 1024 spp, max 8 bounces) rendered in full on the GPU; nine
+    full-width rows spread over the frame are checked against the oracle at the full 1024 spp (17.7 M
+    samples), plus size-independent properties of the whole frame."""
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 1920, 1080, 64, 4
     r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED)
@@ -417,7 +417,8 @@ def test_headline_config_strip_vs_oracle(rtm, oracle):
     assert np.isfinite(img).all() and img.min() >= 0.0
     st, arr, n = oracle.load_scene(oracle.scene_path("cornellBoxSetting.json"), width=1920, height=1080,
                                    samples=64, super_samples=4)
-    for rows in ((0, 1), (539, 540)):
+    for rows in ((0, 1), (134, 135), (269, 270), (404, 405), (539, 540), (674, 675), (809, 810), (944, 945),
+                 (1079, 1080)):
         ref, _ = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=8, seed=0x5EED,
                                                               row_begin=rows[0], row_end=rows[1]))
         err = float(np.max(np.abs(img[rows[0]:rows[1]] - ref)))
