@@ -66,11 +66,16 @@ def cpu_baseline(cfg, budget_rows):
                    threads=threads, structure=1, want_counters=False)
     dt_ref = time.perf_counter() - t1
     samples_ref = max(1, budget_rows // 8) * cfg["width"] * cfg["samples"] * cfg["super_samples"] ** 2
+    t2 = time.perf_counter()
+    _, c1 = _oracle.render(st, arr, n, _oracle.make_options(mode=1, max_bounces=cfg["max_bounces"], seed=cfg["seed"],
+                                                            row_begin=r0, row_end=r0 + 1), threads=1, structure=0)
+    dt_1 = time.perf_counter() - t2
     return {
         "value": cnt["samples"] / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": f"rows {r0}..{r0 + budget_rows} of the headline frame at full 1024 spp "
                   f"({cnt['samples']} samples, {dt:.2f} s wall, OpenMP per-pixel parallel)",
         "reference_loop_structure_value": samples_ref / dt_ref / 1e6,
+        "single_thread_value": c1["samples"] / dt_1 / 1e6,
         "casts_per_sample": cnt["casts"] / cnt["samples"],
         "d4_fraction": cnt["sphere_tests_d4"] / max(1, cnt["sphere_tests"]),
     }
