@@ -375,6 +375,76 @@ def test_record_overflow_fails_loudly(rtm):
         _gpu_image(rtm, data, "repaired", 5000, 1, want=("f64",))
 
 
+def _oracle_view(oracle, data):
+    st, arr, n = data.to_c()
+    return (oracle.Settings.from_buffer_copy(bytes(st)),
+            (oracle.Sphere * max(n, 1)).from_buffer_copy(bytes(arr)), n)
+
+
+def _mk(rtm, pos, r, col, em):
+    return rtm.SphereObject(rtm.vec3(*pos), r, rtm.Material(rtm.vec3(*col), rtm.vec3(*em)))
+
+
+EDGE_SCENES = {
+    # camera inside one sphere, a second one touching the camera ray tangentially
+    "inside-and-tangent": lambda rtm: ([_mk(rtm, (0, 0, 0), 30, (.6, .7, .8), (.1, 0, 0)),
+                                        _mk(rtm, (1, 0, 5), 1, (.9, .9, .1), (0, 2, 0))], (0, 0, -3), 1.0),
+    # radius 0 and a sphere behind the camera
+    "degenerate-radius": lambda rtm: ([_mk(rtm, (0, 0, 4), 0.0, (.5, .5, .5), (1, 1, 1)),
+                                       _mk(rtm, (0, 0, -20), 5, (.5, .5, .5), (3, 3, 3)),
+                                       _mk(rtm, (0, -102, 0), 100, (.8, .8, .8), (0, 0, 0))], (0, 0, -3), 1.5),
+    # albedo above 1 (RR always passes: only the cap or a miss ends a path) and a negative colour
+    "albedo-above-one": lambda rtm: ([_mk(rtm, (0, 0, 0), 12, (1.5, 1.2, 1.0), (0, 0, 0)),
+                                      _mk(rtm, (0, 9, 0), 3, (-0.5, -0.2, -0.1), (4, 4, 4)),
+                                      _mk(rtm, (3, -2, 1), 1.5, (0.2, 0.3, 0.4), (0, 0, .5))], (0, 0, -5), 1.2),
+    # every sphere black (kd = 0, colorKD = 0/0 never used) and emissive
+    "all-black": lambda rtm: ([_mk(rtm, (0, 0, 6), 2, (0, 0, 0), (.5, .25, .125)),
+                               _mk(rtm, (-3, 1, 7), 2, (0, 0, 0), (0, 1, 0))], (0, 0, -3), 1.0),
+    # thresholds of Intersect: origin a hair above a huge sphere (t1 inside [1e-5, 0.001])
+    "grazing-thresholds": lambda rtm: ([_mk(rtm, (0, -1000.0005, 0), 1000, (.7, .7, .7), (0, 0, 0)),
+                                        _mk(rtm, (0, 50, 0), 30, (0, 0, 0), (2, 2, 2))], (0, 0.0, -3), 1.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_SCENES))
+def test_edge_case_scenes_vs_oracle(rtm, oracle, name):
+    objs, origin, fov = EDGE_SCENES[name](rtm)
+    cam = rtm.Camera(rtm.vec3(*origin), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), fov)
+    data = rtm.SettingData(width=45, height=27, samples=3, superSamples=2, camera=cam, object=objs)
+    ost, oarr, n = _oracle_view(oracle, data)
+    for mode, mb in (("repaired", 8), ("repaired", 3), ("literal", -1)):
+        m = oracle.MODE_REPAIRED if mode == "repaired" else oracle.MODE_LITERAL
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=17, height=27))
+        for v in (0, 1, 4, 8):
+            out, stats = _gpu_image(rtm, data, mode, mb, 17, want=("f64",), variant=v)
+            assert np.allclose(out["f64"], ref, rtol=0, atol=PIXEL_TOL, equal_nan=True), (name, mode, mb, v)
+            assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"]), (name, mode, mb, v)
+
+
+def test_degenerate_camera_gives_the_same_nans(rtm, oracle):
+    """upVec parallel to the view direction: Cross(direction, up) = 0, its Normalize is 0/0 and every
+    primary ray is NaN (src/Renderer.cpp:203).  The reference then renders black (NaN rays miss); so
+    must the GPU, in both modes."""
+    base = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    cam = rtm.Camera(rtm.vec3(0, 0, -10), rtm.vec3(0, 0, 0), rtm.vec3(0, 0, 1), 2.0)
+    data = rtm.SettingData(width=24, height=16, samples=2, superSamples=1, camera=cam, object=base.object)
+    ost, oarr, n = _oracle_view(oracle, data)
+    for mode, m in (("repaired", oracle.MODE_REPAIRED), ("literal", oracle.MODE_LITERAL)):
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=8, seed=1, height=16))
+        out, stats = _gpu_image(rtm, data, mode, 8, 1, want=("f64", "u8"))
+        assert np.array_equal(out["f64"], ref, equal_nan=True) and not ref.any()
+        assert stats["casts"] == cnt["casts"] == 24 * 16 * 2
+
+
+def test_one_pixel_one_sample(rtm, oracle):
+    data = rtm.LoadData(oracle.scene_path("simpleSetting1.json")).data
+    data.width, data.height, data.samples, data.superSamples = 1, 1, 1, 1
+    ost, oarr, n = _oracle_view(oracle, data)
+    ref, _ = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=5, height=1))
+    out, stats = _gpu_image(rtm, data, "repaired", -1, 5)
+    assert np.array_equal(out["f64"], ref) and stats["samples"] == 1
+
+
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
