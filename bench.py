@@ -8,9 +8,9 @@
 One "step" = one full pass of the hot path over the headline workload (BASELINE.json configs[2]):
 Cornell box (tests/golden/scenes/cornellBoxSetting.json, unchanged), 1920x1080, 1024 spp
 (superSamples 4 x samples 64), repaired (L1) semantics, max 8 bounces, fp64, seed 0x5EED, rendered
-into the HBM-resident float3 accumulation buffer.  With N > 1 the image is split into N contiguous
-row strips, one per rank (total work fixed => "strong"), and one RCCL gather to rank 0 ends every
-step inside the timed region.  metric = Msamples/s = W*H*spp / s, whole job.
+into the HBM-resident float3 accumulation buffer.  With N > 1 the image is dealt out in interleaved
+8-row bands (band b -> rank b mod N; total work fixed => "strong"), and one RCCL gather to rank 0
+ends every step inside the timed region.  metric = Msamples/s = W*H*spp / s, whole job.
 
 Extra objects on the JSON line:
   roofline     — the binding roof of the render kernel is the fp64 vector ALU, so
@@ -96,6 +96,8 @@ def main():
                     help="BASELINE.json configs: c2 Cornell 512x512x256spp, c3 headline (default), c4 Cornell 4K x 4096spp, "
                          "c5 100k-sphere stress scene 1080p x 256spp (use --rows to bound it)")
     ap.add_argument("--rows", default="", help="render only rows a:b of the frame (value counts those samples)")
+    ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
+                    help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --same-device rehearses the N-rank path on one GPU")
@@ -148,7 +150,7 @@ def main():
     from raytracingmin_amd.distributed import StripRenderer
     sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
                        max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant,
-                       rows=(row_lo, row_hi))
+                       rows=(row_lo, row_hi), layout=args.layout)
 
     if args.ab:
         # interleaved rounds in ONE process (guide rule 24): median/min kernel ms per variant
@@ -228,7 +230,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{cfg['scene']} rows {row_lo}:{row_hi} of {cfg['width']}x{cfg['height']} "
                                    f"{spp}spp (SS {cfg['super_samples']} x S {cfg['samples']}), L1 repaired, "
-                                   f"max_bounces {cfg['max_bounces']}, seed 0x5EED, row strips over "
+                                   f"max_bounces {cfg['max_bounces']}, seed 0x5EED, "
+                                   f"{'interleaved 8-row bands' if args.layout == 'bands' else 'row strips'} over "
                                    f"{world} GPU(s) + one gather",
                        "variant": rtm.lib().rtm_variant_name(
                            args.variant if args.variant else (2 if n_spheres <= 256 else 8)).decode(),

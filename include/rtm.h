@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RTM_ABI_VERSION 1
+#define RTM_ABI_VERSION 2
 
 typedef enum rtm_status {
     RTM_OK = 0,
@@ -78,11 +78,16 @@ typedef struct rtm_options {
     int32_t row_end;      /* one past the last row; full image = [0, height)                   */
     int32_t device;       /* HIP device ordinal                                                */
     int32_t variant;      /* kernel variant, 0 = default (see rtm_variant_name)                */
+    int32_t band_count;   /* interleaved bands for multi-GPU load balance: when > 1 the call
+                             renders only the 8-row bands b = band_index, band_index + band_count,
+                             ... of [row_begin,row_end) (band b = rows row_begin + 8b ..) and
+                             stores them back to back; 0 or 1 = every band                     */
+    int32_t band_index;   /* 0 <= band_index < band_count                                       */
 } rtm_options;
 
 /* Per-render counters (sum over the rendered tile); filled when the pointer is non-null. */
 typedef struct rtm_stats {
-    uint64_t samples;     /* primary samples traced = rows*width*SS*SS*S                       */
+    uint64_t samples;     /* primary samples traced = output rows*width*SS*SS*S                */
     uint64_t casts;       /* PathTracing invocations (ray casts)                               */
     uint64_t bounces;     /* casts that continued (RR passed)                                  */
     uint64_t draws;       /* RNG draws consumed                                                */
@@ -96,6 +101,9 @@ const char* rtm_last_error_detail(void);   /* thread-local text of the last fail
 int rtm_device_count(int* count);          /* RTM_ERR_NO_DEVICE if the HIP runtime has none    */
 int rtm_num_variants(void);
 const char* rtm_variant_name(int variant);
+
+/* Rows a call with these options renders and stores (row_end - row_begin unless banded). */
+int rtm_output_rows(const rtm_options* options);
 
 /* ---- the hot path: Renderer::Render's pixel/sample loop (src/Renderer.cpp:215-250) ----
  * Renders rows [row_begin,row_end) of the image into caller-owned DEVICE buffers; any of the

@@ -38,7 +38,7 @@ class rtm_settings(C.Structure):
 class rtm_options(C.Structure):
     _fields_ = [("mode", C.c_int32), ("max_bounces", C.c_int32), ("seed", C.c_uint64),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("device", C.c_int32),
-                ("variant", C.c_int32)]
+                ("variant", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32)]
 
 
 class rtm_stats(C.Structure):
@@ -58,6 +58,7 @@ SIGNATURES = {
     "rtm_strerror": (C.c_char_p, [C.c_int]),
     "rtm_last_error_detail": (C.c_char_p, []),
     "rtm_device_count": (C.c_int, [_P(C.c_int)]),
+    "rtm_output_rows": (C.c_int, [_P(rtm_options)]),
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
     "rtm_render_device": (C.c_int, [_P(rtm_settings), C.c_void_p, C.c_size_t, C.c_int,
@@ -114,7 +115,7 @@ def lib():
         for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if L.rtm_abi_version() != 1:
+        if L.rtm_abi_version() != 2:
             raise ImportError("librtm_hip.so has an unexpected ABI version")
         _lib = L
     return _lib

@@ -15,6 +15,7 @@ const char* last_error();
 // device path (rtm_kernels.hip)
 int device_count(int* count);
 int num_variants();
+int output_rows(const rtm_options* opt);
 const char* variant_name(int v);
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int spheres_on_device,
                   const rtm_options* opt, double* out64, float* out32, uint8_t* out8, void* stream,

@@ -41,6 +41,7 @@ struct RenderParams {
     SceneView scene;
     int W, H, S, SS;
     int row_begin, row_end;
+    int band_count, band_index;  // interleaved 8-row bands (rtm_options); 1, 0 = every band
     int tiles_x;
     int mode, max_bounces;
     unsigned total_samples;  // SS*SS*S per pixel
@@ -58,6 +59,10 @@ struct RenderParams {
     unsigned* __restrict__ pool_next;       // bump allocator
     unsigned pool_slots;
     unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
+    // sample split (SPLIT kernels): `split` waves per tile, wave f traces samples [f*split_len, (f+1)*split_len)
+    unsigned n_tiles, split, split_len;
+    double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_len samples
+    double* __restrict__ contrib;  // [tile][total_samples - split_len][3][64]: per-sample terms of waves 1..
 };
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -137,9 +142,17 @@ __device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsign
 }
 
 // src/Renderer.cpp:246-254: image[] += acc; optional float3 / 8-bit views of the same pixel
+// Image row of row `sub` (0..7) of this call's band `local_band`: the call renders bands
+// band_index, band_index + band_count, ... of [row_begin, row_end) and stores them back to back.
+__device__ __forceinline__ int band_row(const RenderParams& P, int local_band, int sub) {
+    return P.row_begin + (local_band * P.band_count + P.band_index) * 8 + sub;
+}
+
 __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, int x, int y, D3 acc) {
     if (!valid) return;
-    const size_t o = ((size_t)(y - P.row_begin) * P.W + x) * 3;
+    const int rel = y - P.row_begin;
+    const int out_row = (P.band_count > 1) ? ((rel >> 3) / P.band_count) * 8 + (rel & 7) : rel;
+    const size_t o = ((size_t)out_row * P.W + x) * 3;
     const double r = 0.0 + acc.x, g = 0.0 + acc.y, b = 0.0 + acc.z;  // :246-248
     if (P.out64) {
         P.out64[o] = r;
@@ -172,8 +185,14 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //           are what the unrolled sphere chunk needs to stay under 128 VGPRs without scratch spills
 //   STAMP   diagnostic build: s_memtime around the three segments of an iteration (never timed itself)
 //   PACK8   max_bounces <= 8 and n <= 256: hit records packed in a 64-bit register, no LDS stack
+//   SPLIT   P.split waves per tile, each tracing a contiguous range of the pixel's samples.  Wave 0
+//           accumulates as usual and leaves its accumulator in P.partial; the others store every
+//           sample's term (src/Renderer.cpp:240-242, after the clamp) to P.contrib, and
+//           split_finalize_kernel adds them IN THE REFERENCE'S ORDER, so the image does not change by
+//           a bit.  Used when a strip has too few tiles to keep every SIMD busy to the end (few rows
+//           per GPU, small images): the launch's tail is then the spread of per-tile cost.
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
-          bool STAMP = false, bool PACK8 = false>
+          bool STAMP = false, bool PACK8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -218,9 +237,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     auto pixel_xy = [&](int& px, int& py) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        const int tx = blockIdx.x % P.tiles_x, ty = blockIdx.x / P.tiles_x;
+        const unsigned tile = SPLIT ? blockIdx.x % P.n_tiles : blockIdx.x;
+        const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
         px = tx * 8 + (l & 7);
-        py = P.row_begin + ty * 8 + (l >> 3);
+        py = band_row(P, ty, l >> 3);
     };
     int x, y;
     pixel_xy(x, y);
@@ -231,13 +251,18 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
     D3 acc = d3(0, 0, 0);
 
-    unsigned n = valid ? 0u : P.total_samples;  // sample index ((sx-1)*SS + (sy-1))*S + s
-    int left_in_sub = P.S;                      // samples left before the sub-pixel changes
-    D3 pdir = primary_dir_lds(P, cam, x, y, 1, 1);
+    // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
+    const unsigned split_f = SPLIT ? blockIdx.x / P.n_tiles : 0u;
+    const unsigned n_first = SPLIT ? split_f * P.split_len : 0u;
+    const unsigned n_end = SPLIT ? n_first + P.split_len : P.total_samples;
+    unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
+    int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
+    const int sub_first = (int)(n_first / (unsigned)P.S);
+    D3 pdir = primary_dir_lds(P, cam, x, y, sub_first / P.SS + 1, sub_first % P.SS + 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
     const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
-    RngStream rng = rng_open(pkey, 0u);
+    RngStream rng = rng_open(pkey, n_first);
     if constexpr (PARK) {
         park[0 * 64 + lane] = 0.0;
         park[1 * 64 + lane] = 0.0;
@@ -258,7 +283,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     const bool pow2 = P.inv_s != 0.0;  // wave-uniform
 
     unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
-    while (n < P.total_samples) {
+    while (n < n_end) {
         D3 term;
         bool cont;
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
@@ -291,7 +316,14 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             // power-of-two divisors are applied as multiplications.
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
             const D3 add = clamp01_d3(cal);
-            if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
+            if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
+                const unsigned tile = blockIdx.x % P.n_tiles;
+                double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_len) * 192;
+                const unsigned o = (n - P.split_len) * 192u + (unsigned)lane;
+                row[o] = add.x;
+                row[o + 64] = add.y;
+                row[o + 128] = add.z;
+            } else if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
                 park[0 * 64 + lane] += add.x;
                 park[1 * 64 + lane] += add.y;
                 park[2 * 64 + lane] += add.z;
@@ -301,7 +333,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             ++n;
             if (--left_in_sub == 0) {
                 left_in_sub = P.S;
-                if (n < P.total_samples) {
+                if (n < n_end) {
                     const int sub = (int)(n / (unsigned)P.S);
                     int px, py;
                     pixel_xy(px, py);
@@ -340,7 +372,14 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 
     if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
-    {
+    if constexpr (SPLIT) {
+        if (split_f == 0) {
+            double* dst = P.partial + (size_t)(blockIdx.x % P.n_tiles) * 192 + lane;
+            dst[0] = acc.x;
+            dst[64] = acc.y;
+            dst[128] = acc.z;
+        }
+    } else {
         int px, py;
         pixel_xy(px, py);
         store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
@@ -351,6 +390,34 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         wave_add_counter(P.counters + 2, pc.draws);
         if (stack.overflow) atomicOr(P.counters + 3, 1ull);
     }
+}
+
+// Second half of a SPLIT render: image[pixel] = (((partial + term[split_len]) + term[split_len+1]) + ...),
+// the accumulation order of src/Renderer.cpp:241-242.  One wave per tile; the loads are 512-byte rows
+// and independent of the adds, so the kernel streams P.contrib at HBM rate (1536 B per pixel sample).
+__global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P) {
+    const int lane = threadIdx.x;
+    const unsigned tile = blockIdx.x;
+    const double* part = P.partial + (size_t)tile * 192 + lane;
+    D3 acc = d3(part[0], part[64], part[128]);
+    const unsigned ns = P.total_samples - P.split_len;
+    const double* row = P.contrib + (size_t)tile * ns * 192 + lane;
+    unsigned m = 0;
+    for (; m + 8 <= ns; m += 8) {
+        double v[8][3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k][0] = row[(size_t)(m + k) * 192];
+            v[k][1] = row[(size_t)(m + k) * 192 + 64];
+            v[k][2] = row[(size_t)(m + k) * 192 + 128];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = acc + d3(v[k][0], v[k][1], v[k][2]);
+    }
+    for (; m < ns; ++m) acc = acc + d3(row[(size_t)m * 192], row[(size_t)m * 192 + 64], row[(size_t)m * 192 + 128]);
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int px = tx * 8 + (lane & 7), py = band_row(P, ty, lane >> 3);
+    store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,7 +448,7 @@ __global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderPar
     const int tiles_x4 = (P.tiles_x + 3) / 4;
     const int tx = (blockIdx.x % tiles_x4) * 4 + wave, ty = blockIdx.x / tiles_x4;
     const int x = tx * 8 + (lane & 7);
-    const int y = P.row_begin + ty * 8 + (lane >> 3);
+    const int y = band_row(P, ty, lane >> 3);
     const bool valid = (x < P.W) && (y < P.row_end);
     const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
 
@@ -811,6 +878,21 @@ struct DeviceScene {
     ~DeviceScene() { release(); }
 };
 
+// Rows a call renders and stores: the whole strip, or its bands band_index, band_index + band_count, ...
+// (8 rows each; the last band of the strip may be shorter).
+int output_rows(const rtm_options* opt) {
+    const int span = opt->row_end - opt->row_begin;
+    if (span <= 0) return 0;
+    if (opt->band_count <= 1) return span;
+    const int bands = (span + 7) / 8;
+    if (opt->band_index < 0 || opt->band_index >= bands) return 0;
+    const int mine = (bands - opt->band_index + opt->band_count - 1) / opt->band_count;
+    int rows = mine * 8;
+    const int last = opt->band_index + (mine - 1) * opt->band_count;
+    if (last == bands - 1 && span % 8) rows -= 8 - span % 8;
+    return rows;
+}
+
 static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt) {
     if (!st || !opt || (!sp && n)) {
         set_last_error("null argument");
@@ -822,6 +904,10 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
     }
     if (opt->row_begin < 0 || opt->row_end > st->height || opt->row_begin > opt->row_end) {
         set_last_error("row range outside the image");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->band_count < 0 || (opt->band_count > 1 && (opt->band_index < 0 || opt->band_index >= opt->band_count))) {
+        set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
     if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {
@@ -849,9 +935,10 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
                                       "fast-math-lds-tables-chunk8-nopark-pack8", "fast-math-lds-tables-chunk8-park-ldsrecords",
                                       "diagnostic-stamped (segment cycle shares, not for timing)",
-                                      "wavefront-lds-scene-tiles"};
+                                      "wavefront-lds-scene-tiles",
+                                      "fast-math-lds-tables-chunk8-park-pack8-sample-split"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -874,6 +961,8 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.SS = st->super_samples;
     P.row_begin = opt->row_begin;
     P.row_end = opt->row_end;
+    P.band_count = opt->band_count > 1 ? opt->band_count : 1;
+    P.band_index = opt->band_count > 1 ? opt->band_index : 0;
     P.tiles_x = (st->width + 7) / 8;
     P.mode = opt->mode;
     P.max_bounces = opt->max_bounces;
@@ -909,21 +998,23 @@ static size_t debug_lds_pad() {
 }
 
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
-          bool TRY_PACK8 = false>
+          bool TRY_PACK8 = false, bool SPLIT = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad();
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
         if (P.max_bounces >= 0 && P.max_bounces <= 8) {
-            render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true><<<grid, 64, tab, stream>>>(P);
+            render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT><<<grid, 64, tab, stream>>>(P);
             return;
         }
     }
     if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP><<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, false, SPLIT>
+            <<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP><<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP, false, SPLIT>
+            <<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
 template <typename RecT>
@@ -953,7 +1044,12 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
+        if (P.split > 1) {
+            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true>(P, grid * P.split, stream);
+            split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
+        } else {
+            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
+        }
     } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
         launch_render_depth<MathFast, true, 8, uint8_t, 4, false, false, true>(P, grid, stream);
     } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
@@ -964,6 +1060,31 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
         else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
     }
+}
+
+// Sample split of the default kernel.  A launch with fewer tiles than a few rounds of resident waves
+// (256 CUs x 4 SIMDs x 4 waves on MI355X) ends with SIMDs idling while the costliest tiles finish:
+// measured max/mean per-tile cost on the Cornell box is ~1.27 (profiles/r1/strip_balance.txt).  Such
+// launches get `split` waves per tile; the smallest power of two that yields >= 6 rounds, while the
+// term buffer (1536 B per pixel-tile sample beyond wave 0's) stays within the budget.
+static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
+    static const long env = [] {
+        const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, k = k waves per tile
+        return e ? std::strtol(e, nullptr, 10) : 0L;
+    }();
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const unsigned slots = (unsigned)cus * 16u;
+    auto fits = [&](unsigned f) {
+        if (f < 2 || total_samples % f != 0 || total_samples / f < 8) return false;
+        const double bytes = (double)n_tiles * (double)(total_samples - total_samples / f) * 1536.0;
+        return bytes <= 24.0 * 1024 * 1024 * 1024 && (double)(total_samples - total_samples / f) * 1536.0 < 4.0e9;
+    };
+    if (env > 0) return (env > 1 && fits((unsigned)env)) ? (unsigned)env : 1u;
+    unsigned f = 1;
+    while ((unsigned long long)n_tiles * f < 6ull * slots && fits(f * 2)) f *= 2;
+    if (forced && f == 1 && fits(2)) f = 2;
+    return f;
 }
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
@@ -1044,6 +1165,23 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
     return RTM_OK;
 }
 
+// Work buffers are hipMallocAsync/hipFreeAsync pairs; without a release threshold the default pool
+// hands multi-GB buffers back to the driver at every synchronisation and re-maps them per call.
+static void keep_stream_ordered_memory(int device) {
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int d : done)
+        if (d == device) return;
+    done.push_back(device);
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+        uint64_t keep = ~(uint64_t)0;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+}
+
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
                   const rtm_options* opt, double* out64, float* out32, uint8_t* out8,
                   void* stream_v, rtm_stats* stats) {
@@ -1051,7 +1189,8 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     if (rc != RTM_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_v;
     RTM_HIP_CHECK(hipSetDevice(opt->device));
-    const int rows = opt->row_end - opt->row_begin;
+    keep_stream_ordered_memory(opt->device);
+    const int rows = output_rows(opt);
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (rows == 0) return RTM_OK;
 
@@ -1087,6 +1226,24 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     } pool_free{pool, stream};
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
+    // sample split (default kernel only): per-sample terms of waves 1.. in a stream-ordered buffer
+    int variant = opt->variant;
+    double* split_ws = nullptr;
+    P.n_tiles = grid;
+    P.split = 1;
+    P.split_len = P.total_samples;
+    if ((variant == kVariantAuto || variant == kVariantSplit) && n <= (size_t)kLdsTableMaxSpheres) {
+        P.split = choose_split(grid, P.total_samples, opt->device, variant == kVariantSplit);
+        variant = kVariantFastLds;
+        if (P.split > 1) {
+            P.split_len = P.total_samples / P.split;
+            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_len) * 192;
+            RTM_HIP_CHECK(hipMallocAsync((void**)&split_ws, (part + terms) * sizeof(double), stream));
+            P.partial = split_ws;
+            P.contrib = split_ws + part;
+        }
+    }
+    PoolFree split_free{reinterpret_cast<unsigned char*>(split_ws), stream};
     unsigned long long* stamps = nullptr;
     if (opt->variant == 7) {
         RTM_HIP_CHECK(hipMalloc((void**)&stamps, (size_t)grid * 4 * sizeof(unsigned long long)));
@@ -1107,7 +1264,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         rc = run_wavefront(P, rows, stream);
         if (rc != RTM_OK) return rc;
     } else {
-        launch_render(opt->variant, P, grid, tiles_y, stream);
+        launch_render(variant, P, grid, tiles_y, stream);
     }
     RTM_HIP_CHECK(hipGetLastError());
     if (stamps) {  // diagnostic variant: print the per-wave segment shares
@@ -1150,7 +1307,7 @@ int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rt
     int rc = validate(st, sp, n, opt);
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipSetDevice(opt->device));
-    const size_t vals = (size_t)(opt->row_end - opt->row_begin) * st->width * 3;
+    const size_t vals = (size_t)output_rows(opt) * st->width * 3;
     double* d64 = nullptr;
     float* d32 = nullptr;
     uint8_t* d8 = nullptr;
@@ -1178,6 +1335,10 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
                      uint32_t* out_casts) {
     if (!opt || (!sp && n) || !org || !dir || !out) {
         set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (opt->band_count < 0 || (opt->band_count > 1 && (opt->band_index < 0 || opt->band_index >= opt->band_count))) {
+        set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
     if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {

@@ -3,7 +3,7 @@
 //   rtm_cli [-?] [-json <file>] [-sampleJson]            (the reference's flags, same defaults)
 //           [--width N] [--height N] [--samples N] [--superSamples N] [--spp N]
 //           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM]
-//           [--gpus N] [--virtual-strips N]      (row strips over N GPUs + one RCCL gather)
+//           [--gpus N] [--virtual-strips N]      (interleaved 8-row bands over N GPUs + one RCCL gather)
 //
 // Flow of the reference: pick the JSON (default settingData.json), create the sample JSON when it
 // does not exist, load, render, write <stem>.jpg (quality 60) and <stem>.bmp with stem "result".
@@ -32,7 +32,7 @@ static void usage() {
         "--spp N : samples = N / superSamples^2\n"
         "--mode literal|repaired (default repaired), --max-bounces N (default -1 = unlimited)\n"
         "--seed N, --device N, --out STEM (default result)\n"
-        "--gpus N : row strips over N GPUs of this node, one RCCL gather; --virtual-strips N : N strips on one GPU\n");
+        "--gpus N : interleaved 8-row bands over N GPUs of this node, one RCCL gather; --virtual-strips N : N parts on one GPU\n");
 }
 
 int main(int argc, char* argv[]) {

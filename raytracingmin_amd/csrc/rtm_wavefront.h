@@ -40,7 +40,8 @@ struct WfState {
 
 __device__ __forceinline__ void wf_pixel_xy(const RenderParams& P, unsigned p, int& x, int& y) {
     x = (int)(p % (unsigned)P.W);
-    y = P.row_begin + (int)(p / (unsigned)P.W);
+    const int lr = (int)(p / (unsigned)P.W);  // row of this call's compact output
+    y = band_row(P, lr >> 3, lr & 7);
 }
 
 __global__ __launch_bounds__(256) void wf_init_kernel(const RenderParams P, const WfState S) {

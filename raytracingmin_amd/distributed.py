@@ -1,5 +1,6 @@
-"""Image tiling across the GPUs of one node: one process per GPU, contiguous row strips, one
-gather to rank 0 at the end of a render.
+"""Image tiling across the GPUs of one node: one process per GPU, interleaved 8-row bands (band b of
+the frame belongs to rank b mod N, so every rank gets the same mix of cheap and costly rows) or
+contiguous row strips, and one gather to rank 0 at the end of a render.
 
 Pixels are independent and every sample's RNG stream is keyed by the GLOBAL pixel index, so the
 assembled N-rank image is bit-identical to the 1-rank image.  The scene is replicated (tiny).
@@ -22,6 +23,56 @@ def partition_rows(height: int, world: int) -> List[Tuple[int, int]]:
         t0, t1 = r * tiles // world, (r + 1) * tiles // world
         out.append((min(t0 * TILE_ROWS, height), min(t1 * TILE_ROWS, height)))
     return out
+
+
+def band_row_index(row_begin: int, row_end: int, world: int, rank: int) -> np.ndarray:
+    """Image rows, in output order, of the call (band_count, band_index) = (world, rank) over
+    [row_begin, row_end): the mirror of rtm_output_rows / band_row in the kernels."""
+    span = row_end - row_begin
+    bands = (span + TILE_ROWS - 1) // TILE_ROWS
+    rows = [np.arange(b * TILE_ROWS, min((b + 1) * TILE_ROWS, span)) for b in range(rank, bands, max(world, 1))]
+    return row_begin + (np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64))
+
+
+_index_cache = {}
+
+
+def _band_index_tensors(span, world, device):
+    key = (span, world, str(device))
+    if key not in _index_cache:
+        import torch
+        _index_cache[key] = [torch.as_tensor(band_row_index(0, span, world, r), device=device) for r in range(world)]
+    return _index_cache[key]
+
+
+def gather_bands(local, row_begin, row_end, rank, world, dst=0, group=None):
+    """Gather per-rank band stacks (tensor [rows_r, W, C]) and put the bands back in image order on
+    `dst`.  One collective (equal-size buffers, padded to the largest stack); the de-interleave is one
+    index_copy per rank on the root.  Returns [row_end - row_begin, W, C] on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()
+    index = _band_index_tensors(row_end - row_begin, world, local.device)
+    max_rows = max(len(i) for i in index)
+    rows = len(index[rank])
+    assert local.shape[0] == rows, (local.shape, rows)
+    if rows == max_rows:
+        send = local.contiguous()
+    else:
+        send = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:rows] = local
+    bufs = None
+    if rank == dst:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    full = torch.empty((row_end - row_begin,) + tuple(local.shape[1:]), dtype=local.dtype, device=send.device)
+    for r in range(world):
+        if len(index[r]):
+            full.index_copy_(0, index[r], bufs[r][: len(index[r])])
+    return full
 
 
 def gather_strips(local, strips, rank, world, dst=0, group=None):
@@ -51,13 +102,17 @@ def gather_strips(local, strips, rank, world, dst=0, group=None):
 
 
 class StripRenderer:
-    """Rank-local renderer of one row strip plus the end-of-step gather (bench.py's step)."""
+    """Rank-local renderer of this rank's share of the rows plus the end-of-step gather (bench.py's
+    step).  layout "bands": interleaved 8-row bands (default); "strips": contiguous strips."""
 
     def __init__(self, data, rank=0, world=1, device=0, mode="repaired", max_bounces=-1,
-                 seed=0x5EED, variant=0, want="f32", rows=None):
+                 seed=0x5EED, variant=0, want="f32", rows=None, layout="bands"):
         from .renderer import Renderer
-        self.data, self.rank, self.world = data, rank, world
+        if layout not in ("bands", "strips"):
+            raise ValueError(f"unknown layout {layout!r}")
+        self.data, self.rank, self.world, self.layout = data, rank, world, layout
         lo, hi = rows if rows else (0, data.height)
+        self.range = (lo, hi)
         self.strips = [(lo + b, lo + e) for b, e in partition_rows(hi - lo, world)]
         self.rows = self.strips[rank]
         self.want = want
@@ -70,13 +125,19 @@ class StripRenderer:
         import torch
         if events is not None:
             events[0].record()
-        out, st = self.renderer.render_rows_device(self.rows[0], self.rows[1], want=(self.want,),
-                                                   stats=stats)
+        if self.layout == "bands" and self.world > 1:
+            out, st = self.renderer.render_rows_device(self.range[0], self.range[1], want=(self.want,),
+                                                       stats=stats, band=(self.world, self.rank))
+        else:
+            out, st = self.renderer.render_rows_device(self.rows[0], self.rows[1], want=(self.want,),
+                                                       stats=stats)
         if events is not None:
             events[1].record()
         local = out[self.want]
-        if self.world > 1:
-            self.image = gather_strips(local, self.strips, self.rank, self.world)
-        else:
+        if self.world == 1:
             self.image = local
+        elif self.layout == "bands":
+            self.image = gather_bands(local, self.range[0], self.range[1], self.rank, self.world)
+        else:
+            self.image = gather_strips(local, self.strips, self.rank, self.world)
         return st

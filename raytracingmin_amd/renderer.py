@@ -30,22 +30,27 @@ class Renderer:
         self.image = np.zeros((data.height, data.width, 3), dtype=np.float64)  # src/Renderer.cpp:21
         self.stats = None
 
-    def _options(self, row_begin, row_end):
+    def _options(self, row_begin, row_end, band=None):
         o = rtm_options()
         o.mode, o.max_bounces, o.seed = self.mode, self.max_bounces, self.seed
         o.row_begin, o.row_end = int(row_begin), int(row_end)
         o.device, o.variant = self.device, self.variant
+        if band is not None:  # (count, index): only the 8-row bands index, index + count, ...
+            o.band_count, o.band_index = int(band[0]), int(band[1])
         return o
 
     # ---- device-resident render: outputs are torch tensors on the GPU ------------------------
     def render_rows_device(self, row_begin=0, row_end=None, want=("f32",), stats=True,
-                           stream=None):
-        """Render rows [row_begin, row_end) into torch CUDA tensors; returns (dict, stats)."""
+                           stream=None, band=None):
+        """Render rows [row_begin, row_end) into torch CUDA tensors; returns (dict, stats).
+        band=(count, index) renders only every count-th 8-row band of the range, stored back to back
+        (include/rtm.h, rtm_options.band_count)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("Renderer needs a HIP device; there is no CPU fallback")
         row_end = self.data.height if row_end is None else row_end
-        rows, W = row_end - row_begin, self.data.width
+        opt = self._options(row_begin, row_end, band)
+        rows, W = _lib.lib().rtm_output_rows(C.byref(opt)), self.data.width
         dev = torch.device("cuda", self.device)
         out = {}
         if "f64" in want:
@@ -55,7 +60,6 @@ class Renderer:
         if "u8" in want:
             out["u8"] = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
         st, arr, n = self.data.to_c()
-        opt = self._options(row_begin, row_end)
         s = rtm_stats()
         hip_stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out and rows > 0 else None
@@ -65,9 +69,10 @@ class Renderer:
         return out, (s.as_dict() if stats else None)
 
     # ---- host-buffer render (the blocking C entry point) ------------------------------------
-    def render_rows(self, row_begin=0, row_end=None, want=("f64",)):
+    def render_rows(self, row_begin=0, row_end=None, want=("f64",), band=None):
         row_end = self.data.height if row_end is None else row_end
-        rows, W = row_end - row_begin, self.data.width
+        opt = self._options(row_begin, row_end, band)
+        rows, W = _lib.lib().rtm_output_rows(C.byref(opt)), self.data.width
         out = {}
         if "f64" in want:
             out["f64"] = np.zeros((rows, W, 3), dtype=np.float64)
@@ -76,7 +81,6 @@ class Renderer:
         if "u8" in want:
             out["u8"] = np.zeros((rows, W, 3), dtype=np.uint8)
         st, arr, n = self.data.to_c()
-        opt = self._options(row_begin, row_end)
         s = rtm_stats()
         ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
         _lib.check(_lib.lib().rtm_render(C.byref(st), arr, n, C.byref(opt), ptr("f64"), ptr("f32"),

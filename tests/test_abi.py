@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"{n} declared in include/rtm.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().rtm_abi_version() == 1
+    assert _lib.lib().rtm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.rtm_camera) == 80
     assert C.sizeof(_lib.rtm_sphere) == 80
     assert C.sizeof(_lib.rtm_settings) == 96
-    assert C.sizeof(_lib.rtm_options) == 32
+    assert C.sizeof(_lib.rtm_options) == 40
     assert C.sizeof(_lib.rtm_stats) == 40
     # the oracle's view of the same PODs
     import _oracle

@@ -27,15 +27,20 @@ def _worker(rank, world, port, scene, dims, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import raytracingmin_amd as rtm
-        from raytracingmin_amd.distributed import gather_strips, partition_rows
+        from raytracingmin_amd.distributed import StripRenderer, gather_strips, partition_rows
         data = rtm.LoadData(scene).data
         data.width, data.height, data.samples, data.superSamples = dims
         strips = partition_rows(data.height, world)
         r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED, device=0)
         out, stats = r.render_rows_device(strips[rank][0], strips[rank][1], want=("f64",))
         img = gather_strips(out["f64"].cpu(), strips, rank, world)  # gloo gathers host tensors
+        # bench.py's step: interleaved 8-row bands (rtm_options.band_count/band_index) + one gather
+        sr = StripRenderer(data, rank=rank, world=world, device=0, mode="repaired", max_bounces=8, seed=0x5EED,
+                           want="f64", layout="bands")
+        sr.step()
         if rank == 0:
             q.put(img.numpy())
+            q.put(sr.image.numpy())
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -54,6 +59,7 @@ def test_strips_from_n_ranks_equal_single_rank_frame(world, dims):
     for p in procs:
         p.start()
     img = q.get()
+    img_bands = q.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -61,3 +67,4 @@ def test_strips_from_n_ranks_equal_single_rank_frame(world, dims):
     data.width, data.height, data.samples, data.superSamples = dims
     full, _ = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED).render_rows(want=("f64",))
     assert np.array_equal(img.view(np.uint64), full["f64"].view(np.uint64))
+    assert np.array_equal(img_bands.view(np.uint64), full["f64"].view(np.uint64))

@@ -445,6 +445,66 @@ def test_one_pixel_one_sample(rtm, oracle):
     assert np.array_equal(out["f64"], ref) and stats["samples"] == 1
 
 
+@pytest.mark.parametrize("w,h,s,ss,mb", [(64, 40, 8, 2, 8),    # split on sub-pixel boundaries
+                                          (45, 27, 8, 3, 8),    # 72 samples: ranges start inside a sub-pixel
+                                          (40, 24, 24, 1, -1),  # unlimited depth (LDS records + pool)
+                                          (33, 17, 5, 2, 12)])  # 20 samples: two waves of 10
+def test_sample_split_is_bit_identical(rtm, oracle, w, h, s, ss, mb):
+    """Several waves per tile, each tracing a range of the pixel's samples; the terms are added in the
+    reference's order afterwards (src/Renderer.cpp:241-242), so nothing may change."""
+    st, arr, n = oracle.load_scene(oracle.scene_path("cornellBoxSetting.json"), width=w, height=h, samples=s,
+                                   super_samples=ss)
+    ref, cnt = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=mb, seed=99, height=h))
+    data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+    names = [rtm.lib().rtm_variant_name(v).decode() for v in range(rtm.lib().rtm_num_variants())]
+    split = [i for i, nm in enumerate(names) if nm.endswith("sample-split")][0]
+    whole, st_whole = _gpu_image(rtm, data, "repaired", mb, 99, variant=2)
+    parts, st_parts = _gpu_image(rtm, data, "repaired", mb, 99, variant=split)
+    for k in ("f64", "f32", "u8"):
+        assert np.array_equal(whole[k], parts[k]), k
+    assert np.array_equal(parts["f64"], ref)
+    assert {k: st_parts[k] for k in ("samples", "casts", "bounces", "draws")} == \
+           {k: st_whole[k] for k in ("samples", "casts", "bounces", "draws")}
+    assert st_parts["casts"] == cnt["casts"]
+    # a strip of the frame, too (tile rows are relative to row_begin)
+    strip, _ = _gpu_image(rtm, data, "repaired", mb, 99, want=("f64",), rows=(8, h), variant=split)
+    assert np.array_equal(strip["f64"], ref[8:])
+
+
+@pytest.mark.parametrize("scene,w,h,n_big", [("cornellBoxSetting.json", 50, 45, 0), ("simpleSetting1.json", 40, 64, 0),
+                                             ("stress", 40, 29, 300)])
+def test_interleaved_bands_reassemble_the_frame(rtm, oracle, scene, w, h, n_big):
+    """rtm_options.band_count/band_index (the multi-GPU deal of 8-row bands): the stacks of all ranks,
+    put back by band_row_index, are the frame bit for bit; so are the counters' sums."""
+    from raytracingmin_amd.distributed import band_row_index
+    if scene == "stress":
+        data = rtm.make_stress_scene(n_big, seed=7)
+        data.width, data.height, data.samples, data.superSamples = w, h, 2, 2
+    else:
+        data = rtm.LoadData(oracle.scene_path(scene)).data
+        data.width, data.height, data.samples, data.superSamples = w, h, 4, 2
+    for variant in (0, 1, 4, 8, 9):
+        full, st_full = _gpu_image(rtm, data, "repaired", 8, 3, want=("f64", "u8"), variant=variant)
+        for lo, hi, world in ((0, h, 3), (8, h - 3, 2), (0, h, 8)):
+            got = np.full_like(full["f64"], np.nan)
+            casts = 0
+            for rank in range(world):
+                r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3, variant=variant)
+                out, st = r.render_rows(lo, hi, want=("f64", "u8"), band=(world, rank))
+                idx = band_row_index(lo, hi, world, rank)
+                assert out["f64"].shape[0] == len(idx)
+                got[idx] = out["f64"]
+                assert np.array_equal(out["u8"], full["u8"][idx])
+                casts += st["casts"]
+            assert np.array_equal(got[lo:hi], full["f64"][lo:hi]), (variant, lo, hi, world)
+            assert np.isnan(got[:lo]).all() and np.isnan(got[hi:]).all()
+            if (lo, hi) == (0, h):
+                assert casts == st_full["casts"]
+    with pytest.raises(rtm.RtmError):
+        rtm.Renderer(data, mode="repaired", max_bounces=8).render_rows(0, h, band=(2, 2))
+
+
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
