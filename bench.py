@@ -214,7 +214,7 @@ def main():
         rank_samples = stats["samples"]  # samples one launch of this rank processed
         flops_per_launch = f_sample * rank_samples
         achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-        rows0 = sr.rows[1] - sr.rows[0]
+        rows0 = stats["samples"] // (cfg["width"] * spp)  # rows this rank's launch stores
         alg_bytes = rows0 * cfg["width"] * 12 + n_spheres * 96
         hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
