@@ -155,3 +155,39 @@ def test_rng_range_and_exactness(oracle):
     # distinct seeds / pixels / samples / indices give distinct streams
     assert L.rtmo_rng_u01(1, 0, 0, 0) != L.rtmo_rng_u01(2, 0, 0, 0)
     assert len(set(us.tolist())) > 0.99 * us.size
+
+
+# ---- frozen outputs of the oracle (tests/golden/frozen, made by tests/golden/make_fixtures.py) -------
+def _fixtures_module():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_fixtures.py")
+    spec = importlib.util.spec_from_file_location("make_fixtures", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return a.shape == b.shape and np.array_equal(a.view(np.uint64 if a.itemsize == 8 else np.uint32),
+                                                     b.view(np.uint64 if b.itemsize == 8 else np.uint32))
+    return np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["intersect_1k", "pathtrace_1k", "image_cornellBoxSetting", "image_simpleSetting1",
+                                   "image_simpleSetting2", "image_settingData"])
+def test_oracle_reproduces_frozen_fixtures(oracle, which):
+    """Any change to oracle/cpu_ref.c that moves a bit of these committed outputs is caught here,
+    without the reference."""
+    mf = _fixtures_module()
+    frozen = np.load(os.path.join(mf.OUT, which + ".npz"))
+    if which == "intersect_1k":
+        now = mf.intersect_cases()
+    elif which == "pathtrace_1k":
+        now = mf.pathtrace_cases()
+    else:
+        now = mf.image_case(which[len("image_"):] + ".json")
+    assert sorted(frozen.files) == sorted(now)
+    for k in frozen.files:
+        assert _same(frozen[k], now[k]), k

@@ -220,6 +220,57 @@ def test_path_tracing_batch_vs_oracle(rtm, oracle, scene, max_bounces):
     assert worst <= PIXEL_TOL
 
 
+FROZEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frozen")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64) if a.dtype == np.float64 else a
+
+
+def test_frozen_seam_fixtures(rtm):
+    """The committed expected outputs (tests/golden/frozen, frozen from the pinned oracle) for the two
+    seams below the renderer — no oracle involved at test time."""
+    import ctypes as C
+    from raytracingmin_amd import _lib
+    z = np.load(os.path.join(FROZEN, "intersect_1k.npz"))
+    n = len(z["radius"])
+    sph = (_lib.rtm_sphere * n)()
+    for i in range(n):
+        for k in range(3):
+            sph[i].center[k] = z["center"][i, k]
+        sph[i].radius = float(z["radius"][i])
+    for mode in ("literal", "repaired"):
+        hit, t, nrm = rtm.intersect_batch(sph, z["org"], z["dir"], mode=mode)
+        assert np.array_equal(hit, z[f"hit_{mode}"])
+        assert np.array_equal(_bits(t), _bits(z[f"t_{mode}"]))
+        assert np.array_equal(_bits(nrm), _bits(z[f"normal_{mode}"]))
+    assert 200 < int(z["hit_repaired"].sum()) < n
+    z = np.load(os.path.join(FROZEN, "pathtrace_1k.npz"))
+    data = rtm.LoadData(os.path.join(os.path.dirname(FROZEN), "scenes", "cornellBoxSetting.json")).data
+    for tag, mb in (("cap8", 8), ("unlimited", -1)):
+        L, draws, casts = rtm.path_tracing_batch(data, z["org"], z["dir"], mode="repaired", max_bounces=mb,
+                                                 seed=int(z["seed"]))
+        assert np.array_equal(draws, z[f"draws_{tag}"]) and np.array_equal(casts, z[f"casts_{tag}"])
+        assert np.array_equal(_bits(L), _bits(z[f"radiance_{tag}"]))
+
+
+@pytest.mark.parametrize("scene", ["cornellBoxSetting", "simpleSetting1", "simpleSetting2", "settingData"])
+def test_frozen_images(rtm, scene):
+    """64x64, 16 spp frames of every shipped scene against the committed raw float64 images."""
+    z = np.load(os.path.join(FROZEN, f"image_{scene}.npz"))
+    path = os.path.join(os.path.dirname(FROZEN), "scenes", scene + ".json")
+    for mode in ("repaired", "literal"):
+        if f"image_{mode}" not in z.files:
+            continue
+        data = rtm.LoadData(path, literal_loader=(mode == "literal")).data
+        data.width, data.height, data.samples, data.superSamples = 64, 64, 4, 2
+        for variant in (0, 1, 9):
+            out, stats = _gpu_image(rtm, data, mode, -1, 0x5EED, want=("f64",), variant=variant)
+            assert np.array_equal(_bits(out["f64"]), _bits(z[f"image_{mode}"])), (mode, variant)
+            assert stats["casts"] == int(z[f"casts_{mode}"]) and stats["draws"] == int(z[f"draws_{mode}"])
+
+
 def _gpu_image(rtm, data, mode, max_bounces, seed, want=("f64", "f32", "u8"), rows=None, variant=0):
     r = rtm.Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, variant=variant)
     rb, re = rows if rows else (0, data.height)
