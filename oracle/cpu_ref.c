@@ -58,6 +58,15 @@ void rtmo_cross(const double a[3], const double b[3], double out[3]) {
 double rtmo_magnitude(const double a[3]) { return magnitude3(v3_from(a)); }
 void rtmo_normalize(const double a[3], double out[3]) { v3_to(normalize3(v3_from(a)), out); }
 
+/* The host libm's sin / cos exactly as the path calls them (src/Renderer.cpp:93-94 restated below),
+ * for checking the device's sincos over every argument the RNG can produce. */
+void rtmo_sin_cos_array(const double* x, size_t n, double* out_sin, double* out_cos) {
+    for (size_t i = 0; i < n; ++i) {
+        out_sin[i] = sin(x[i]);
+        out_cos[i] = cos(x[i]);
+    }
+}
+
 /* src/SettingData.h:14-16 — float return: the max is rounded to float (Q10) */
 float rtmo_kd(const rtm_sphere* s) {
     double m = s->color[0] < s->color[1] ? s->color[1] : s->color[0]; /* std::max(x, y) */

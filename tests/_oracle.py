@@ -91,6 +91,8 @@ def lib():
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.rtmo_rng_u01.restype = C.c_double
         L.rtmo_rng_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.rtmo_sin_cos_array.restype = None
+        L.rtmo_sin_cos_array.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rtmo_normalize.restype = None
         L.rtmo_normalize.argtypes = [_D3, _D3]
         L.rtmo_magnitude.restype = C.c_double
@@ -199,6 +201,14 @@ def normalize(v):
     out = _D3()
     lib().rtmo_normalize(_D3(*v), out)
     return [out[0], out[1], out[2]]
+
+
+def sin_cos(x):
+    """The host libm's sin, cos (what oracle/cpu_ref.c calls) for an array of arguments."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().rtmo_sin_cos_array(x.ctypes.data, x.size, s.ctypes.data, c.ctypes.data)
+    return s, c
 
 
 def fnv(arr):

@@ -117,6 +117,24 @@ def test_sincos_small_matches_ocml(rtm):
     assert np.array_equal(_probe(rtm, 13, x).view(np.uint64), _probe(rtm, 6, x).view(np.uint64))
 
 
+def test_device_sincos_vs_host_libm_on_every_rng_argument(rtm, oracle):
+    """cos(r1), sin(r1) of src/Renderer.cpp:93-94 for EVERY r1 = 2*pi*u the RNG can produce, device
+    against the libm the oracle is linked with.  Neither is required to be correctly rounded; the
+    count of arguments on which they differ is what makes whole images bit-identical or not."""
+    differing = 0
+    worst = 0.0
+    for lo in range(0, 1 << 23, 1 << 21):
+        k = np.arange(lo, lo + (1 << 21), dtype=np.float64)
+        r1 = 6.283185307179586 * ((2 * k + 1) / 16777216.0)
+        hs, hc = oracle.sin_cos(r1)
+        ds, dc = _probe(rtm, 12, r1), _probe(rtm, 13, r1)
+        differing += int(np.count_nonzero(ds.view(np.uint64) != hs.view(np.uint64)))
+        differing += int(np.count_nonzero(dc.view(np.uint64) != hc.view(np.uint64)))
+        worst = max(worst, float(np.abs(ds - hs).max()), float(np.abs(dc - hc).max()))
+    print(f"device sincos vs host libm over all 2^23 arguments: {differing} differing values, max abs err {worst:.3e}")
+    assert worst <= 1.2e-16
+
+
 def test_fast_sqrtf_exhaustive(rtm):
     """The unscaled float sqrt of the shading block equals sqrtf for EVERY float in [2^-96, FLT_MAX]
     (1.9e9 values, checked on the device) and its guard rejects everything outside."""
