@@ -224,7 +224,8 @@ def main():
         if world == 1 and headline and args.variant == 0 and os.path.exists(tpath):
             traffic = json.load(open(tpath))["bytes_per_launch"]  # measured PMC bytes, committed profile
         line = {
-            "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp", "value": value,
+            "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp" if args.workload == "c3" else
+                      f"Msamples/s (W*H*spp/s), BASELINE configs workload {args.workload}", "value": value,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -234,12 +235,13 @@ def main():
                                    f"{'interleaved 8-row bands' if args.layout == 'bands' else 'row strips'} over "
                                    f"{world} GPU(s) + one gather",
                        "variant": rtm.lib().rtm_variant_name(
-                           args.variant if args.variant else (2 if n_spheres <= 256 else 8)).decode(),
+                           args.variant if args.variant else (2 if n_spheres <= 256 else 11)).decode(),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": traffic,
-                "kernel": "render_tiles_kernel", "kernel_ms": kernel_ms,
+                "kernel": "render_tiles_kernel" if n_spheres <= 256 else "wf_nearest_scalar_kernel + wf_shade_kernel",
+                "kernel_ms": kernel_ms,
                 "flops_per_sample": f_sample,
                 "note": "no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM "
                         "traffic; peak counts FMA as 2 flops but parity forbids contraction, so the "

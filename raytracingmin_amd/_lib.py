@@ -85,7 +85,9 @@ SIGNATURES = {
 }
 # test hook (not in rtm.h)
 _EXTRA = {"rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-          "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)])}
+          "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+          "rtm_debug_wf_nearest": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p])}
 
 _lib = None
 

@@ -78,6 +78,12 @@ int rtm_debug_component_bench(int which, const rtm_sphere* sp, size_t n, int rep
     RTM_GUARD(rtm::component_bench(which, sp, n, reps, blocks, lds_pad, cycles_per_rep))
 }
 
+/* test hook: the large-scene nearest-hit kernels on caller-given rays (kind 0 LDS tiles, 1 scalar
+ * stream, 2 scalar stream + rejection test) */
+int rtm_debug_wf_nearest(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
+                         int32_t* out_id, double* out_t) {
+    RTM_GUARD(rtm::wf_nearest_probe(kind, sp, n, org, dir, n_rays, out_id, out_t))
+}
 /* test hook: exhaustive device self-checks, returns the number of mismatches */
 int rtm_debug_selfcheck(int kind, unsigned long long* mismatches) { RTM_GUARD(rtm::selfcheck(kind, mismatches)) }
 

@@ -936,9 +936,10 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "fast-math-lds-tables-chunk8-nopark-pack8", "fast-math-lds-tables-chunk8-park-ldsrecords",
                                       "diagnostic-stamped (segment cycle shares, not for timing)",
                                       "wavefront-lds-scene-tiles",
-                                      "fast-math-lds-tables-chunk8-park-pack8-sample-split"};
+                                      "fast-math-lds-tables-chunk8-park-pack8-sample-split",
+                                      "wavefront-scalar-scene", "wavefront-scalar-scene-reject"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -1095,7 +1096,7 @@ static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, 
     wf_nearest_kernel<MathFast, TILE, K, R><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
 }
 
-static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
+static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, int scalar_scene) {
     // (TILE, K, R) = (512 spheres per LDS tile, 4 per chunk, 1 ray per lane): profiles/r1/wf_tune.txt —
     // smaller chunks or 2-4 rays per lane (fewer LDS reads per ray, fewer waves) were 0-50 % slower
     WfState S;
@@ -1116,7 +1117,9 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
     struct Free {
         void* p;
         hipStream_t s;
-        ~Free() { (void)hipFreeAsync(p, s); }
+        ~Free() {
+            if (p) (void)hipFreeAsync(p, s);
+        }
     } free_ws{ws, stream};
     unsigned char* q = ws;
     auto take = [&](size_t b) {
@@ -1139,6 +1142,18 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
     S.active[0] = (unsigned*)take(N * 4);
     S.active[1] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
+    RenderParams PS = P;  // + the rejection test's per-sphere data
+    double* aux = nullptr;
+    if (scalar_scene == 2) {
+        const int n_pad = (P.scene.n + 7) & ~7;
+        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad + 2) * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 2 * sizeof(double), stream));
+        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
+                                                                    reinterpret_cast<unsigned long long*>(aux));
+        PS.scene.bounds = aux;
+        PS.scene.wprime = aux + 2;
+    }
+    Free free_aux{aux, stream};
     const unsigned grid = (unsigned)((N + 255) / 256);
     const unsigned init_counts[2] = {S.npix, 0u};
     RTM_HIP_CHECK(hipMemcpyAsync(S.n_active, init_counts, sizeof init_counts, hipMemcpyHostToDevice, stream));
@@ -1155,7 +1170,12 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream) {
         }
         const unsigned g = (na + 255) / 256;
         RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-        launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
+        if (scalar_scene == 2)
+            wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(PS, S, cur);
+        else if (scalar_scene == 1)
+            wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(PS, S, cur);
+        else
+            launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
         wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
         RTM_HIP_CHECK(hipGetLastError());
         RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + (cur ^ 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1258,10 +1278,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
     // auto: scenes beyond the LDS-table size go through the wavefront pipeline
-    const bool wavefront = opt->variant == kVariantWavefront ||
+    const bool wavefront = opt->variant == kVariantWavefront || opt->variant == kVariantWavefrontScalar ||
+                           opt->variant == kVariantWavefrontReject ||
                            (opt->variant == kVariantAuto && n > (size_t)kLdsTableMaxSpheres);
     if (wavefront) {
-        rc = run_wavefront(P, rows, stream);
+        // auto: scalar stream + rejection test (profiles/r1/wf_tune.txt); 8 and 10 stay as A/B twins
+        rc = run_wavefront(P, rows, stream, opt->variant == kVariantWavefront ? 0 : opt->variant == kVariantWavefrontScalar ? 1 : 2);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, tiles_y, stream);
@@ -1504,6 +1526,76 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
     *cycles_per_rep = sum / blocks / reps;
     (void)hipFree(out);
     (void)hipFree(cyc);
+    return RTM_OK;
+}
+
+// Test hook: the large-scene nearest-hit kernels on caller-given rays.  kind 0: LDS tiles, 1: scalar
+// stream, 2: scalar stream + rejection test.  Host buffers; out_id/out_t per ray.
+int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
+                     int32_t* out_id, double* out_t) {
+    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 2 || n_rays > 0x7FFFFFFFull)
+        return RTM_ERR_INVALID_ARGUMENT;
+    DeviceScene ds;
+    int rc = ds.upload(sp, n, 0, nullptr);
+    if (rc != RTM_OK) return rc;
+    RenderParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    WfState S;
+    std::memset(&S, 0, sizeof S);
+    const size_t N = n_rays;
+    S.npix = (unsigned)N;
+    const int n_pad = ((int)n + 7) & ~7;
+    unsigned char* ws = nullptr;
+    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad + 2) * 8 + 256;
+    RTM_HIP_CHECK(hipMalloc((void**)&ws, bytes));
+    struct Free {
+        void* p;
+        ~Free() { (void)hipFree(p); }
+    } free_ws{ws};
+    unsigned char* q = ws;
+    auto take = [&](size_t b) {
+        unsigned char* r = q;
+        q += (b + 15) & ~(size_t)15;
+        return r;
+    };
+    S.org = (double*)take(N * 24);
+    S.dir = (double*)take(N * 24);
+    S.hit_t = (double*)take(N * 8);
+    S.hit_id = (int*)take(N * 4);
+    S.active[0] = (unsigned*)take(N * 4);
+    S.n_active = (unsigned*)take(16);
+    double* aux = (double*)take(((size_t)n_pad + 2) * 8);
+    std::vector<double> soa(N * 3);
+    std::vector<unsigned> ident(N);
+    for (size_t i = 0; i < N; ++i) {
+        ident[i] = (unsigned)i;
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * N + i] = org[i * 3 + k];
+    }
+    RTM_HIP_CHECK(hipMemcpy(S.org, soa.data(), N * 24, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * N + i] = dir[i * 3 + k];
+    RTM_HIP_CHECK(hipMemcpy(S.dir, soa.data(), N * 24, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(S.active[0], ident.data(), N * 4, hipMemcpyHostToDevice));
+    const unsigned counts[2] = {(unsigned)N, 0u};
+    RTM_HIP_CHECK(hipMemcpy(S.n_active, counts, sizeof counts, hipMemcpyHostToDevice));
+    const unsigned g = (unsigned)((N + 255) / 256);
+    if (kind == 2) {
+        RTM_HIP_CHECK(hipMemset(aux, 0, 16));
+        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
+                                                          reinterpret_cast<unsigned long long*>(aux));
+        P.scene.bounds = aux;
+        P.scene.wprime = aux + 2;
+        wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);
+    } else if (kind == 1) {
+        wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256>>>(P, S, 0);
+    } else {
+        launch_wf_nearest<512, 4, 1>(P, S, 0, (unsigned)N, nullptr);
+    }
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipDeviceSynchronize());
+    RTM_HIP_CHECK(hipMemcpy(out_id, S.hit_id, N * 4, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_t, S.hit_t, N * 8, hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 

@@ -250,6 +250,10 @@ struct SceneView {
     const double4* __restrict__ geom;
     const double* __restrict__ mat;
     int n;
+    // large-scene rejection test (rtm_wavefront.h): wprime[i] = r2_i - |c_i|^2 (padded to a multiple of
+    // 8 entries), bounds = {max |c|^2, max r2}
+    const double* __restrict__ wprime = nullptr;
+    const double* __restrict__ bounds = nullptr;
 };
 
 // Wave-uniform geometry fetch.  The tables are never written while a render kernel runs, but the
@@ -375,10 +379,25 @@ __device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int 
         D4[k] = b[k] * b[k] - dot(p_o, p_o) + g[k].w;                       // :200
     }
     if constexpr (EARLY_OUT) {
-        bool any = false;  // a NaN discriminant (literal mode) is "not >= 0": it can never be accepted
+        // "some D4 >= 0" as one compare of the largest discriminant (v_max_f64 skips NaN operands; a
+        // NaN discriminant, literal mode, is "not >= 0": it can never be accepted; -0 counts as >= 0)
+        double top = D4[0];
 #pragma unroll
-        for (int k = 0; k < K; ++k) any = any || (D4[k] >= 0.0);
-        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+        for (int k = 1; k < K; ++k) top = __builtin_fmax(top, D4[k]);
+        if (__builtin_amdgcn_ballot_w64(top >= 0.0) == 0) return;
+        // rare from here on (scenes of many small spheres): one sphere at a time keeps the register
+        // footprint of this path — and with it the occupancy of the whole kernel — small
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (__builtin_amdgcn_ballot_w64(D4[k] >= 0.0) == 0) continue;
+            const double sqk = M::sqrt64(D4[k]);  // :205 (D4 < 0 gives NaN: no hit)
+            const double t1 = b[k] - sqk, t2 = b[k] + sqk;
+            const double t = (t1 > 0.001) ? t1 : t2;
+            const bool accept = (t < dis) && !(t < (double)1e-5f);
+            dis = accept ? t : dis;
+            hit_object = accept ? i0 + k : hit_object;
+        }
+        return;
     }
     M::template sqrt64_batch<K>(D4, sq);                           // :205 (D4 < 0 gives NaN: no hit)
 #pragma unroll

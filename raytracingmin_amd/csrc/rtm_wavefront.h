@@ -148,6 +148,124 @@ __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, c
         }
 }
 
+// Auxiliary per-sphere data for the rejection test of wf_nearest_scalar_kernel.
+__global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __restrict__ geom, const int n, const int n_pad,
+                                                           double* __restrict__ wprime, unsigned long long* __restrict__ bounds) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n) {  // padding: a sphere that can never pass the test
+        wprime[i] = -HUGE_VAL;
+        return;
+    }
+    const double4 g = geom[i];
+    const double cc = g.x * g.x + g.y * g.y + g.z * g.z;
+    wprime[i] = g.w - cc;
+    // max over non-negative doubles == max over their bit patterns; NaN / negative values stay out
+    if (cc >= 0.0) atomicMax(bounds + 0, (unsigned long long)__double_as_longlong(cc));
+    if (g.w >= 0.0) atomicMax(bounds + 1, (unsigned long long)__double_as_longlong(g.w));
+}
+
+// The nearest-hit pass with the sphere list read through the SCALAR cache instead of LDS tiles, and a
+// conservative REJECTION TEST in front of the reference's arithmetic.
+//  * The walk is wave-uniform, so a chunk of K spheres is a few s_loads into SGPRs (two SGPR buffers,
+//    one in flight while the other is tested) and the VALU takes its sphere operands straight from
+//    SGPRs: no LDS round trip, no tile staging, no barriers.  All waves stream the same list, so the
+//    scalar caches and L2 absorb the re-reads (measured: identical speed with an always-hit list).
+//  * 99.99 % of (ray, sphere) pairs of such a scene have a negative discriminant and are only ever
+//    REJECTED; for that decision the reference's 16 non-fused operations are not needed.  With
+//    P = c - o:  D4 = (P.d)^2 - P.P + r2 = (c.d - o.d)^2 + (r2 - c.c) + 2 c.o - o.o, which is 8 FMAs per
+//    sphere from (cx, cy, cz, w' = r2 - c.c) and per-ray constants.  Both this value and the
+//    reference's are within  72 u (1 + d.d)(max c.c + o.o + max r2)  of the exact discriminant
+//    (u = 2^-53; standard dot-product bounds), so a sphere whose fused value is below
+//    -margin, margin = 2048 u (...), has a negative reference discriminant and cannot be hit.  Any
+//    other chunk runs the reference's arithmetic (sphere_chunk_g), which alone decides hits: the
+//    image cannot change.  NaN / infinite operands make the margin NaN / infinite; such rays accept
+//    nothing in the reference either (every comparison with their t is false).
+template <class M, int K, int BLOCK, bool REJECT>
+__global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderParams P, const WfState S, const int cur) {
+    static_assert(K == 4, "one 32-byte w' load per chunk");
+    const unsigned na = S.n_active[cur];
+    if (blockIdx.x * (unsigned)BLOCK >= na) return;
+    const unsigned i = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+    const bool live = i < na;
+    const unsigned N = S.npix;
+    const unsigned p = S.active[cur][live ? i : na - 1];
+    const D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
+    const D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
+    double dis = DBL_MAX;
+    int id = -1;
+    const int n = P.scene.n;
+
+    // per-ray constants of the rejection test
+    const double od = __builtin_fma(org.z, dir.z, __builtin_fma(org.y, dir.y, org.x * dir.x));
+    const double oo = __builtin_fma(org.z, org.z, __builtin_fma(org.y, org.y, org.x * org.x));
+    const double dd = __builtin_fma(dir.z, dir.z, __builtin_fma(dir.y, dir.y, dir.x * dir.x));
+    const D3 o2 = d3(org.x + org.x, org.y + org.y, org.z + org.z);
+    double neg_margin = 0.0;
+    if constexpr (REJECT) {
+        typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+        ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
+        neg_margin = -(0x1p-42 * ((1.0 + dd) * (bnd[0] + oo + bnd[1])));
+    }
+    auto load_w = [&](int j, double (&w)[K]) {
+        typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+        ConstF64Ptr q = (ConstF64Ptr)(unsigned long long)(P.scene.wprime + j);
+#pragma unroll
+        for (int k = 0; k < K; ++k) w[k] = q[k];
+    };
+    auto test = [&](const double4 (&g)[K], const double (&w)[K], int j) {
+        if constexpr (REJECT) {
+            double top = -HUGE_VAL;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double bq = __builtin_fma(g[k].z, dir.z, __builtin_fma(g[k].y, dir.y, __builtin_fma(g[k].x, dir.x, -od)));
+                const double tq = w[k] + __builtin_fma(g[k].z, o2.z, __builtin_fma(g[k].y, o2.y, __builtin_fma(g[k].x, o2.x, -oo)));
+                top = __builtin_fmax(top, __builtin_fma(bq, bq, tq));
+            }
+            if (__builtin_amdgcn_ballot_w64(top >= neg_margin) == 0) return;
+        }
+        sphere_chunk_g<M, K, true>(g, j, org, dir, dis, id);
+    };
+
+    // two chunk buffers (A, B) in SGPRs: while one is tested the other is in flight.  Scalar loads
+    // return out of order, so the only wait is "all of them": each buffer is requested right after
+    // the wait that delivered the other one and has a whole chunk's arithmetic to arrive.
+    const int n_pairs = n / (2 * K);
+    const int n_full = n_pairs * 2 * K;
+    double4 a[K], b[K];
+    double wa[K], wb[K];
+    if (n_pairs > 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = load_geom_uniform(P.scene.geom, k);
+        if constexpr (REJECT) load_w(0, wa);
+    }
+    for (int j = 0; j < n_full; j += 2 * K) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) b[k] = load_geom_uniform(P.scene.geom, j + K + k);
+        if constexpr (REJECT) load_w(j + K, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        test(a, wa, j);
+        const int jn = (j + 2 * K < n_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) a[k] = load_geom_uniform(P.scene.geom, jn + k);
+        if constexpr (REJECT) load_w(jn, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        test(b, wb, j + K);
+    }
+    for (int j = n_full; j < n; ++j) {
+        double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
+        sphere_chunk_g<M, 1, true>(g1, j, org, dir, dis, id);
+    }
+    if (live) {
+        S.hit_id[p] = id;
+        S.hit_t[p] = dis;
+    }
+}
+
 // Shade / fold / accumulate / regenerate for the active pixels, then compaction of the survivors.
 __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderParams P, const WfState S, const int cur) {
     const unsigned na = S.n_active[cur];

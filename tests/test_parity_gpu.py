@@ -135,6 +135,75 @@ def test_device_sincos_vs_host_libm_on_every_rng_argument(rtm, oracle):
     assert worst <= 1.2e-16
 
 
+def _wf_nearest(rtm, kind, sph, n, org, d):
+    from raytracingmin_amd import _lib
+    org = np.ascontiguousarray(org, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    ids = np.zeros(len(org), dtype=np.int32)
+    t = np.zeros(len(org), dtype=np.float64)
+    _lib.check(rtm.lib().rtm_debug_wf_nearest(kind, sph, n, org.ctypes.data, d.ctypes.data, len(org), ids.ctypes.data,
+                                              t.ctypes.data), "wf_nearest")
+    return ids, t
+
+
+def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
+    """wf_nearest_scalar_kernel<REJECT> drops a sphere when a fused 8-FMA discriminant is below
+    -margin.  Rays aimed at the silhouettes of spheres, with the true discriminant swept through zero
+    from 1e-6 down to rounding noise on both sides, plus grazing/tangent, inside-the-sphere, far-away
+    and non-finite rays, must get the id and distance of the kernels that only use the reference's
+    arithmetic — and of the oracle."""
+    from raytracingmin_amd import _lib
+    rng = np.random.default_rng(77)
+    n = 1000
+    data = rtm.make_stress_scene(n, seed=99)
+    _, arr, _ = data.to_c()
+    c = np.array([[arr[i].center[k] for k in range(3)] for i in range(n)])
+    r = np.array([arr[i].radius for i in range(n)], dtype=np.float64)
+    rays_o, rays_d = [], []
+    for rep in range(40000):
+        i = int(rng.integers(n))
+        o = rng.uniform(-60, 60, 3) if rep % 4 else c[int(rng.integers(n))] + rng.normal(size=3) * 0.3
+        P = c[i] - o
+        L = np.linalg.norm(P)
+        if L <= r[i] * 1.01:
+            continue
+        e = np.cross(P, rng.normal(size=3))
+        e /= np.linalg.norm(e)
+        delta = (10.0 ** rng.uniform(-17, -6)) * rng.choice([-1.0, 1.0]) * (rep % 7 != 0)
+        s = math.sqrt(max(r[i] * r[i] + delta, 0.0)) / L      # sin(theta): D4 ~ -delta
+        if s >= 1:
+            continue
+        d = math.sqrt(1 - s * s) * P / L + s * e
+        rays_o.append(o)
+        rays_d.append(d if rep % 11 else d * rng.uniform(0.5, 3.0))  # some directions not normalised
+    special = [([0, 0, 0], [np.nan, 0, 1]), ([np.inf, 0, 0], [0, 0, 1]), ([0, 0, 0], [np.inf, 0, 0]),
+               ([1e200, 0, 0], [1, 0, 0]), ([0, 0, 0], [0, 0, 0]), ([0, 0, 0], [1e-200, 0, 0])]
+    for o, d in special:
+        rays_o.append(np.array(o, dtype=np.float64))
+        rays_d.append(np.array(d, dtype=np.float64))
+    rays_o, rays_d = np.array(rays_o), np.array(rays_d)
+    ref_id, ref_t = _wf_nearest(rtm, 1, arr, n, rays_o, rays_d)
+    for kind in (0, 2):
+        ids, t = _wf_nearest(rtm, kind, arr, n, rays_o, rays_d)
+        assert np.array_equal(ids, ref_id), kind
+        assert np.array_equal(t.view(np.uint64), ref_t.view(np.uint64)), kind
+    hit = ref_id >= 0
+    assert 0.25 < hit.mean() < 0.9  # the sweep straddles the silhouettes
+    oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+    # the oracle's Intersect on the reported sphere gives the reported distance, and no lower-index
+    # sphere of a sample of rays gives a closer or equal one
+    for k in rng.choice(np.flatnonzero(hit), 300, replace=False):
+        h, tt, _ = oracle.intersect(oarr[int(ref_id[k])], rays_o[k], rays_d[k], oracle.MODE_REPAIRED)
+        assert h and tt == ref_t[k]
+    for k in rng.choice(len(rays_o) - len(special), 40, replace=False):
+        best, best_id = np.inf, -1
+        for i in range(n):
+            h, tt, _ = oracle.intersect(oarr[i], rays_o[k], rays_d[k], oracle.MODE_REPAIRED)
+            if h and tt < best and tt > 0:
+                best, best_id = tt, i
+        assert best_id == ref_id[k]
+
+
 def test_fast_sqrtf_exhaustive(rtm):
     """The unscaled float sqrt of the shading block equals sqrtf for EVERY float in [2^-96, FLT_MAX]
     (1.9e9 values, checked on the device) and its guard rejects everything outside."""
