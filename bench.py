@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HEADLINE = dict(scene="cornellBoxSetting.json", width=1920, height=1080, samples=64, super_samples=4,
                 mode="repaired", max_bounces=8, seed=0x5EED)
+PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (packed fp32, FMA = 2 flops)
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # AMD datasheet (FMA = 2 flops); MI355X_MICROARCH.md has fp32 157.3
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md chip table (spec)
 
@@ -235,12 +236,12 @@ def main():
                                    f"{'interleaved 8-row bands' if args.layout == 'bands' else 'row strips'} over "
                                    f"{world} GPU(s) + one gather",
                        "variant": rtm.lib().rtm_variant_name(
-                           args.variant if args.variant else (2 if n_spheres <= 256 else 11)).decode(),
+                           args.variant if args.variant else (2 if n_spheres <= 256 else 12)).decode(),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": traffic,
-                "kernel": "render_tiles_kernel" if n_spheres <= 256 else "wf_nearest_scalar_kernel + wf_shade_kernel",
+                "kernel": "render_tiles_kernel" if n_spheres <= 256 else "wf_nearest_f32_kernel + wf_shade_kernel",
                 "kernel_ms": kernel_ms,
                 "flops_per_sample": f_sample,
                 "note": "no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM "
@@ -250,6 +251,17 @@ def main():
                         "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        if n_spheres > 256 and args.variant in (0, 12):
+            # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
+            # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
+            tests_per_s = stats["casts"] * n_spheres / (kernel_ms * 1e-3)
+            ach = tests_per_s * 16.0 / 1e12
+            line["roofline"].update({
+                "bound": "valu-fp32", "achieved": ach, "peak": PEAK_FP32_VECTOR_TFLOPS, "frac": ach / PEAK_FP32_VECTOR_TFLOPS,
+                "sphere_tests_per_s": tests_per_s, "algorithmic_fp64_tflops": achieved_tflops,
+                "note": "brute force over every sphere; a pair whose discriminant is provably negative is rejected "
+                        "by 8 packed-fp32 FMAs (16 flops, counted here), the rest get the reference's fp64 "
+                        "arithmetic; algorithmic_fp64_tflops prices every pair at the reference's 17 flops"})
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -937,9 +937,10 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "diagnostic-stamped (segment cycle shares, not for timing)",
                                       "wavefront-lds-scene-tiles",
                                       "fast-math-lds-tables-chunk8-park-pack8-sample-split",
-                                      "wavefront-scalar-scene", "wavefront-scalar-scene-reject"};
+                                      "wavefront-scalar-scene", "wavefront-scalar-scene-reject",
+                                      "wavefront-scalar-scene-reject-f32"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -1144,14 +1145,16 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     S.n_active = (unsigned*)take(16);
     RenderParams PS = P;  // + the rejection test's per-sphere data
     double* aux = nullptr;
-    if (scalar_scene == 2) {
+    if (scalar_scene >= 2) {
         const int n_pad = (P.scene.n + 7) & ~7;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad + 2) * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad * 3 + 2) * sizeof(double), stream));
         RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 2 * sizeof(double), stream));
+        float4* g32 = reinterpret_cast<float4*>(aux + 2 + n_pad);
         wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
-                                                                    reinterpret_cast<unsigned long long*>(aux));
+                                                                    reinterpret_cast<unsigned long long*>(aux), g32);
         PS.scene.bounds = aux;
         PS.scene.wprime = aux + 2;
+        PS.scene.geom32 = g32;
     }
     Free free_aux{aux, stream};
     const unsigned grid = (unsigned)((N + 255) / 256);
@@ -1170,7 +1173,9 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
         }
         const unsigned g = (na + 255) / 256;
         RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-        if (scalar_scene == 2)
+        if (scalar_scene == 3)
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(PS, S, cur);
+        else if (scalar_scene == 2)
             wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(PS, S, cur);
         else if (scalar_scene == 1)
             wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(PS, S, cur);
@@ -1279,11 +1284,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     }
     // auto: scenes beyond the LDS-table size go through the wavefront pipeline
     const bool wavefront = opt->variant == kVariantWavefront || opt->variant == kVariantWavefrontScalar ||
-                           opt->variant == kVariantWavefrontReject ||
+                           opt->variant == kVariantWavefrontReject || opt->variant == kVariantWavefrontRejectF32 ||
                            (opt->variant == kVariantAuto && n > (size_t)kLdsTableMaxSpheres);
     if (wavefront) {
-        // auto: scalar stream + rejection test (profiles/r1/wf_tune.txt); 8 and 10 stay as A/B twins
-        rc = run_wavefront(P, rows, stream, opt->variant == kVariantWavefront ? 0 : opt->variant == kVariantWavefrontScalar ? 1 : 2);
+        // auto: scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
+        rc = run_wavefront(P, rows, stream, opt->variant == kVariantWavefront ? 0 : opt->variant == kVariantWavefrontScalar ? 1 :
+                                            opt->variant == kVariantWavefrontReject ? 2 : 3);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, tiles_y, stream);
@@ -1533,7 +1539,7 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
 // stream, 2: scalar stream + rejection test.  Host buffers; out_id/out_t per ray.
 int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                      int32_t* out_id, double* out_t) {
-    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 2 || n_rays > 0x7FFFFFFFull)
+    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 3 || n_rays > 0x7FFFFFFFull)
         return RTM_ERR_INVALID_ARGUMENT;
     DeviceScene ds;
     int rc = ds.upload(sp, n, 0, nullptr);
@@ -1547,7 +1553,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     S.npix = (unsigned)N;
     const int n_pad = ((int)n + 7) & ~7;
     unsigned char* ws = nullptr;
-    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad + 2) * 8 + 256;
+    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 3 + 2) * 8 + 256;
     RTM_HIP_CHECK(hipMalloc((void**)&ws, bytes));
     struct Free {
         void* p;
@@ -1565,7 +1571,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     S.hit_id = (int*)take(N * 4);
     S.active[0] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
-    double* aux = (double*)take(((size_t)n_pad + 2) * 8);
+    double* aux = (double*)take(((size_t)n_pad * 3 + 2) * 8);
     std::vector<double> soa(N * 3);
     std::vector<unsigned> ident(N);
     for (size_t i = 0; i < N; ++i) {
@@ -1580,13 +1586,18 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     const unsigned counts[2] = {(unsigned)N, 0u};
     RTM_HIP_CHECK(hipMemcpy(S.n_active, counts, sizeof counts, hipMemcpyHostToDevice));
     const unsigned g = (unsigned)((N + 255) / 256);
-    if (kind == 2) {
+    if (kind >= 2) {
         RTM_HIP_CHECK(hipMemset(aux, 0, 16));
+        float4* g32 = reinterpret_cast<float4*>(aux + 2 + n_pad);
         wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
-                                                          reinterpret_cast<unsigned long long*>(aux));
+                                                          reinterpret_cast<unsigned long long*>(aux), g32);
         P.scene.bounds = aux;
         P.scene.wprime = aux + 2;
-        wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);
+        P.scene.geom32 = g32;
+        if (kind == 3)
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256>>>(P, S, 0);
+        else
+            wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);
     } else if (kind == 1) {
         wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256>>>(P, S, 0);
     } else {

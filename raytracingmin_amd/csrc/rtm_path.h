@@ -254,6 +254,7 @@ struct SceneView {
     // 8 entries), bounds = {max |c|^2, max r2}
     const double* __restrict__ wprime = nullptr;
     const double* __restrict__ bounds = nullptr;
+    const float4* __restrict__ geom32 = nullptr;  // (float)cx, cy, cz, (float)w' (padded like wprime)
 };
 
 // Wave-uniform geometry fetch.  The tables are never written while a render kernel runs, but the

@@ -150,16 +150,29 @@ __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, c
 
 // Auxiliary per-sphere data for the rejection test of wf_nearest_scalar_kernel.
 __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __restrict__ geom, const int n, const int n_pad,
-                                                           double* __restrict__ wprime, unsigned long long* __restrict__ bounds) {
+                                                           double* __restrict__ wprime, unsigned long long* __restrict__ bounds,
+                                                           float4* __restrict__ geom32) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     if (i >= n) {  // padding: a sphere that can never pass the test
         wprime[i] = -HUGE_VAL;
+        if (geom32) {
+            float* q = reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1);
+            q[0] = q[2] = q[4] = 0.f;
+            q[6] = -HUGE_VALF;
+        }
         return;
     }
     const double4 g = geom[i];
     const double cc = g.x * g.x + g.y * g.y + g.z * g.z;
     wprime[i] = g.w - cc;
+    if (geom32) {  // spheres 2m, 2m+1 interleaved: cx0 cx1 cy0 cy1 cz0 cz1 w0 w1 (operands of packed fp32 math)
+        float* q = reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1);
+        q[0] = (float)g.x;
+        q[2] = (float)g.y;
+        q[4] = (float)g.z;
+        q[6] = (float)(g.w - cc);
+    }
     // max over non-negative doubles == max over their bit patterns; NaN / negative values stay out
     if (cc >= 0.0) atomicMax(bounds + 0, (unsigned long long)__double_as_longlong(cc));
     if (g.w >= 0.0) atomicMax(bounds + 1, (unsigned long long)__double_as_longlong(g.w));
@@ -255,6 +268,125 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderPa
         if constexpr (REJECT) load_w(jn, wa);
         __builtin_amdgcn_sched_barrier(0);
         test(b, wb, j + K);
+    }
+    for (int j = n_full; j < n; ++j) {
+        double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
+        sphere_chunk_g<M, 1, true>(g1, j, org, dir, dis, id);
+    }
+    if (live) {
+        S.hit_id[p] = id;
+        S.hit_t[p] = dis;
+    }
+}
+
+// The rejection test in SINGLE precision (twice the issue rate), in front of the reference arithmetic.
+// Same identity, arranged so that the per-sphere data is (cx, cy, cz, w') as floats:
+//   D4 = (c.d)^2 + c.e + w' + k,   e = 2o - 2(o.d)d,  k = (o.d)^2 - o.o   (per-ray, computed in fp64)
+// = 1 mul + 6 fma + 1 add in fp32.  With u = 2^-24, rounding every input to float and every operation
+// once gives (Higham's gamma_n bounds; sum |c_i||x_i| <= R |x|_1, R^2 = max c.c):
+//   |D4_f32 - D4| <= u [ 11.4 R^2 d.d + 7.3 R |e|_1 + 6.3 |k| + 3.2 (R^2 + max r2) ]
+// plus the fp64-level terms of wf_nearest_scalar_kernel.  The kernel uses 16 u (...) + the fp64
+// margin, rounded up; a chunk none of whose spheres reaches -margin in any lane is skipped, any
+// other chunk loads the fp64 spheres and runs the reference arithmetic.  Overflowing or non-finite
+// operands give an infinite or NaN margin: infinite passes everything (max starts at -inf), and a NaN
+// margin can only come from a non-finite ray, which accepts nothing in the reference either.
+template <class M, int BLOCK, int K, bool PACKED = true>
+__global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParams P, const WfState S, const int cur) {
+    static_assert(K == 4 || K == 8, "one or two 64-byte scalar loads per chunk");
+    const unsigned na = S.n_active[cur];
+    if (blockIdx.x * (unsigned)BLOCK >= na) return;
+    const unsigned i = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+    const bool live = i < na;
+    const unsigned N = S.npix;
+    const unsigned p = S.active[cur][live ? i : na - 1];
+    const D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
+    const D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
+    double dis = DBL_MAX;
+    int id = -1;
+    const int n = P.scene.n;
+
+    typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+    typedef const __attribute__((address_space(4))) float* ConstF32Ptr;
+    ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
+    const double R2 = bnd[0], r2max = bnd[1];
+    const double od = __builtin_fma(org.z, dir.z, __builtin_fma(org.y, dir.y, org.x * dir.x));
+    const double oo = __builtin_fma(org.z, org.z, __builtin_fma(org.y, org.y, org.x * org.x));
+    const double dd = __builtin_fma(dir.z, dir.z, __builtin_fma(dir.y, dir.y, dir.x * dir.x));
+    const double od2 = od + od;
+    const D3 e = d3(__builtin_fma(-od2, dir.x, org.x + org.x), __builtin_fma(-od2, dir.y, org.y + org.y),
+                    __builtin_fma(-od2, dir.z, org.z + org.z));
+    const double kq = __builtin_fma(od, od, -oo);
+    const double R = __builtin_sqrt(R2) * (1.0 + 0x1p-40);
+    const double e1 = __builtin_fabs(e.x) + __builtin_fabs(e.y) + __builtin_fabs(e.z);
+    const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
+    const double m32 = 0x1p-20 * (R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max) + 0x1p-100;
+    const float neg_margin = -(float)((m32 + m64) * (1.0 + 0x1p-20));  // rounded to nearest, pre-inflated
+    const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
+    const float ex = (float)e.x, ey = (float)e.y, ez = (float)e.z, kf = (float)kq;
+
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    struct Pair {
+        f2 x, y, z, w;  // two spheres
+    };
+    auto load32 = [&](int j, Pair (&g)[K / 2]) {
+        ConstF32Ptr q = (ConstF32Ptr)(unsigned long long)(reinterpret_cast<const float*>(P.scene.geom32) + (size_t)j * 4);
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            g[k].x = f2{q[8 * k], q[8 * k + 1]};
+            g[k].y = f2{q[8 * k + 2], q[8 * k + 3]};
+            g[k].z = f2{q[8 * k + 4], q[8 * k + 5]};
+            g[k].w = f2{q[8 * k + 6], q[8 * k + 7]};
+        }
+    };
+    const f2 dx2 = f2{dx, dx}, dy2 = f2{dy, dy}, dz2 = f2{dz, dz}, ex2 = f2{ex, ex}, ey2 = f2{ey, ey}, ez2 = f2{ez, ez},
+             kf2 = f2{kf, kf};
+    auto test = [&](const Pair (&g)[K / 2], int j) {
+        f2 tq[K / 2];
+        f2 top2 = f2{-HUGE_VALF, -HUGE_VALF};
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            if constexpr (PACKED) {
+                const f2 uq = __builtin_elementwise_fma(g[k].z, dz2, __builtin_elementwise_fma(g[k].y, dy2, g[k].x * dx2));
+                const f2 vq = __builtin_elementwise_fma(g[k].z, ez2, __builtin_elementwise_fma(g[k].y, ey2,
+                                  __builtin_elementwise_fma(g[k].x, ex2, kf2))) + g[k].w;
+                tq[k] = __builtin_elementwise_fma(uq, uq, vq);
+            } else {
+                const float u0 = __builtin_fmaf(g[k].z.x, dz, __builtin_fmaf(g[k].y.x, dy, g[k].x.x * dx));
+                const float u1 = __builtin_fmaf(g[k].z.y, dz, __builtin_fmaf(g[k].y.y, dy, g[k].x.y * dx));
+                const float v0 = __builtin_fmaf(g[k].z.x, ez, __builtin_fmaf(g[k].y.x, ey, __builtin_fmaf(g[k].x.x, ex, kf))) + g[k].w.x;
+                const float v1 = __builtin_fmaf(g[k].z.y, ez, __builtin_fmaf(g[k].y.y, ey, __builtin_fmaf(g[k].x.y, ex, kf))) + g[k].w.y;
+                tq[k] = f2{__builtin_fmaf(u0, u0, v0), __builtin_fmaf(u1, u1, v1)};
+            }
+            top2 = __builtin_elementwise_max(top2, tq[k]);  // v_pk_max_f32 skips NaN operands like v_max_f32
+        }
+        const float top = __builtin_fmaxf(top2.x, top2.y);
+        if (__builtin_amdgcn_ballot_w64(top >= neg_margin) == 0) return;
+        // rare: the spheres some lane could not reject get the reference arithmetic, in index order
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float t = (k & 1) ? tq[k / 2].y : tq[k / 2].x;
+            if (__builtin_amdgcn_ballot_w64(t >= neg_margin) == 0) continue;
+            double4 g64[1] = {load_geom_uniform(P.scene.geom, j + k)};
+            sphere_chunk_g<M, 1, true>(g64, j + k, org, dir, dis, id);
+        }
+    };
+
+    const int n_pairs = n / (2 * K);
+    const int n_full = n_pairs * 2 * K;
+    Pair a[K / 2], b[K / 2];
+    if (n_pairs > 0) load32(0, a);
+    for (int j = 0; j < n_full; j += 2 * K) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        load32(j + K, b);
+        __builtin_amdgcn_sched_barrier(0);
+        test(a, j);
+        const int jn = (j + 2 * K < n_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        load32(jn, a);
+        __builtin_amdgcn_sched_barrier(0);
+        test(b, j + K);
     }
     for (int j = n_full; j < n; ++j) {
         double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
