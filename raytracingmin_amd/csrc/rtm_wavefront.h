@@ -218,7 +218,8 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderPa
     if constexpr (REJECT) {
         typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
         ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
-        neg_margin = -(0x1p-42 * ((1.0 + dd) * (bnd[0] + oo + bnd[1])));
+        const double mag = (1.0 + dd) * (bnd[0] + oo + bnd[1]);  // bounds every intermediate of the test
+        neg_margin = (mag < 0x1p1000) ? -(0x1p-42 * mag) : -HUGE_VAL;   // near overflow / non-finite: reject nothing
     }
     auto load_w = [&](int j, double (&w)[K]) {
         typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
@@ -285,11 +286,13 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderPa
 // = 1 mul + 6 fma + 1 add in fp32.  With u = 2^-24, rounding every input to float and every operation
 // once gives (Higham's gamma_n bounds; sum |c_i||x_i| <= R |x|_1, R^2 = max c.c):
 //   |D4_f32 - D4| <= u [ 11.4 R^2 d.d + 7.3 R |e|_1 + 6.3 |k| + 3.2 (R^2 + max r2) ]
-// plus the fp64-level terms of wf_nearest_scalar_kernel.  The kernel uses 16 u (...) + the fp64
-// margin, rounded up; a chunk none of whose spheres reaches -margin in any lane is skipped, any
-// other chunk loads the fp64 spheres and runs the reference arithmetic.  Overflowing or non-finite
-// operands give an infinite or NaN margin: infinite passes everything (max starts at -inf), and a NaN
-// margin can only come from a non-finite ray, which accepts nothing in the reference either.
+// plus underflow (<= 17 x 2^-126 x max(1, |d|, |e|, 2R|d|)) and the fp64-level terms of
+// wf_nearest_scalar_kernel.  The kernel uses 16 u (...) + 2^-110 (1 + d.d + |e|_1 + R^2) + the fp64
+// margin, rounded up; a chunk none of whose spheres reaches -margin in any lane is skipped, and in any
+// other chunk the spheres some lane could not reject get the reference arithmetic, in index order.
+// When the magnitude sum is >= 2^100 (a product could overflow a float) or not finite, the margin is
+// infinite and nothing is rejected; below that every fp32 intermediate is finite, so no NaN can hide
+// a sphere from the max.
 template <class M, int BLOCK, int K, bool PACKED = true>
 __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParams P, const WfState S, const int cur) {
     static_assert(K == 4 || K == 8, "one or two 64-byte scalar loads per chunk");
@@ -319,8 +322,10 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
     const double R = __builtin_sqrt(R2) * (1.0 + 0x1p-40);
     const double e1 = __builtin_fabs(e.x) + __builtin_fabs(e.y) + __builtin_fabs(e.z);
     const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
-    const double m32 = 0x1p-20 * (R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max) + 0x1p-100;
-    const float neg_margin = -(float)((m32 + m64) * (1.0 + 0x1p-20));  // rounded to nearest, pre-inflated
+    const double mag = R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max;  // bounds every fp32 intermediate
+    const double m32 = 0x1p-20 * mag + 0x1p-110 * (1.0 + dd + e1 + R2);     // rounding + underflow
+    // magnitudes that could overflow single precision (or a non-finite ray): reject nothing
+    const float neg_margin = (mag < 0x1p100) ? -(float)((m32 + m64) * (1.0 + 0x1p-20)) : -HUGE_VALF;
     const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
     const float ex = (float)e.x, ey = (float)e.y, ez = (float)e.z, kf = (float)kq;
 
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float t = (k & 1) ? tq[k / 2].y : tq[k / 2].x;
-            if (__builtin_amdgcn_ballot_w64(t >= neg_margin) == 0) continue;
+            if (__builtin_amdgcn_ballot_w64(!(t < neg_margin)) == 0) continue;
             double4 g64[1] = {load_geom_uniform(P.scene.geom, j + k)};
             sphere_chunk_g<M, 1, true>(g64, j + k, org, dir, dis, id);
         }

@@ -189,6 +189,20 @@ def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
         assert np.array_equal(t.view(np.uint64), ref_t.view(np.uint64)), kind
     hit = ref_id >= 0
     assert 0.25 < hit.mean() < 0.95  # the sweep straddles the silhouettes
+    # the same geometry blown up to where single (1e25) or double (1e160) precision products overflow:
+    # the rejection tests must step aside, not hide spheres
+    from raytracingmin_amd import _lib
+    for scale in (1e25, 1e160):
+        big = (_lib.rtm_sphere * n)()
+        for i in range(n):
+            for k in range(3):
+                big[i].center[k] = c[i, k] * scale
+            big[i].radius = min(float(r[i]) * scale, 3.0e38)
+        o_big = rays_o[:4000] * scale
+        want_id, want_t = _wf_nearest(rtm, 1, big, n, o_big, rays_d[:4000])
+        for kind in (2, 3):
+            ids, t = _wf_nearest(rtm, kind, big, n, o_big, rays_d[:4000])
+            assert np.array_equal(ids, want_id) and np.array_equal(t.view(np.uint64), want_t.view(np.uint64)), (scale, kind)
     oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
     # the oracle's Intersect on the reported sphere gives the reported distance, and no lower-index
     # sphere of a sample of rays gives a closer or equal one
