@@ -191,9 +191,22 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //           split_finalize_kernel adds them IN THE REFERENCE'S ORDER, so the image does not change by
 //           a bit.  Used when a strip has too few tiles to keep every SIMD busy to the end (few rows
 //           per GPU, small images): the launch's tail is then the spread of per-tile cost.
+//   DEFER   (with PACK8 + PARK) path ends are queued and folded 64 at a time.  The fold, the /SS/SS/S and
+//           the clamp of a finished path are a pure function of its hit ids, but only ~22 % of the
+//           lanes finish a path in a given iteration, so doing that work on the spot runs ~100
+//           instructions with a fifth of the lanes (13 % of the frame, measured).  Instead the ending
+//           lanes append (records, terminal id) to a wave-shared ring in LDS and start their next
+//           sample at once; whenever 64 entries are waiting, all 64 lanes fold one entry each and leave
+//           the term in LDS, and every owner then adds its terms to its accumulator in the order its
+//           paths ended (a per-lane FIFO of ring positions keeps that order) — the accumulation order
+//           of src/Renderer.cpp:241-242 is untouched.
+constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
+constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
+
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
-          bool STAMP = false, bool PACK8 = false, bool SPLIT = false>
+          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
+    static_assert(!DEFER || (PACK8 && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
@@ -203,6 +216,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* trig = cam + 10;                 // 9 camera doubles + pad
     double* park = trig + kTrigConstCount;   // 16 sincos constants
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
+    // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
+    uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
+    double* fq_out = reinterpret_cast<double*>(fq_in + kFoldRing);
+    unsigned long long* fq_fifo = reinterpret_cast<unsigned long long*>(fq_out + 3 * 64);
+    unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
+    if constexpr (DEFER) fq_pend[lane] = 0u;
     if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
@@ -282,8 +301,103 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     auto pop = [&](int d) -> int { return stack.pop(d); };
     const bool pow2 = P.inv_s != 0.0;  // wave-uniform
 
+    // DEFER: ring indices (wave-uniform) and one pass of the queue
+    unsigned fq_head = 0, fq_tail = 0, fq_count = 0;
+    auto fold_pass = [&]() {
+        const unsigned m = fq_count < 64u ? fq_count : 64u;
+        if ((unsigned)lane < m) {
+            const uint4 e = fq_in[(fq_head + (unsigned)lane) & (kFoldRing - 1)];
+            const D3 L = path_fold_packed8_all(sc, (int)e.z, (unsigned long long)e.x | ((unsigned long long)e.y << 32));
+            const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;  // :240
+            const D3 add = clamp01_d3(cal);
+            fq_out[0 * 64 + lane] = add.x;
+            fq_out[1 * 64 + lane] = add.y;
+            fq_out[2 * 64 + lane] = add.z;
+        }
+        // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
+        for (;;) {
+            const unsigned pend = fq_pend[lane];
+            const unsigned oldest = (unsigned)(fq_fifo[lane] >> (8u * ((pend ? pend : 1u) - 1u))) & 0xFFu;
+            const unsigned rel = (oldest - fq_head) & (kFoldRing - 1);
+            const bool mine = pend != 0u && rel < m;
+            if (__builtin_amdgcn_ballot_w64(mine) == 0) break;
+            if (mine) {
+                if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
+                    const unsigned tile = blockIdx.x % P.n_tiles;
+                    double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_len) * 192;
+                    const unsigned o = ((n - pend) - P.split_len) * 192u + (unsigned)lane;  // n - pend: this entry's sample
+                    row[o] = fq_out[0 * 64 + rel];
+                    row[o + 64] = fq_out[1 * 64 + rel];
+                    row[o + 128] = fq_out[2 * 64 + rel];
+                } else {
+                    park[0 * 64 + lane] += fq_out[0 * 64 + rel];
+                    park[1 * 64 + lane] += fq_out[1 * 64 + rel];
+                    park[2 * 64 + lane] += fq_out[2 * 64 + rel];
+                }
+                fq_pend[lane] = pend - 1u;
+            }
+        }
+        fq_head = (fq_head + m) & (kFoldRing - 1);
+        fq_count -= m;
+    };
+
+    (void)fold_pass;
+    if constexpr (DEFER) {
+        // wave-uniform loop: a lane that has finished its samples idles here, because fold_pass needs
+        // all 64 lanes whatever their own state
+        while (__builtin_amdgcn_ballot_w64(n < n_end) != 0) {
+            bool ended = false, fifo_full = false;
+            if (n < n_end) {
+                D3 term;
+                int hit_id;
+                const bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push,
+                                                       trig, &hit_id);
+                if (!cont) {
+                    // queue this path end: ring position = tail + rank among the lanes ending now
+                    const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
+                    const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
+                    fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32),
+                                       (unsigned)(hit_id < 0 ? P.scene.n : hit_id), 0u};
+                    const unsigned pend = fq_pend[lane] + 1u;
+                    fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
+                    fq_pend[lane] = pend;
+                    fifo_full = pend >= 8u;
+                    ended = true;
+                    // next sample of this pixel (src/Renderer.cpp:236-239)
+                    ++n;
+                    if (--left_in_sub == 0) {
+                        left_in_sub = P.S;
+                        if (n < n_end) {
+                            const int sub = (int)(n / (unsigned)P.S);
+                            int px, py;
+                            pixel_xy(px, py);
+                            pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                            park[3 * 64 + lane] = pdir.x;
+                            park[4 * 64 + lane] = pdir.y;
+                            park[5 * 64 + lane] = pdir.z;
+                        }
+                    }
+                    org = P.cam_org;
+                    dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
+                    depth = 0;
+                    recq = packed8_empty(P.scene.n);
+                    rng = rng_open(pkey, n);
+                }
+            }
+            const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));
+            if (added != 0u) {
+                fq_tail = (fq_tail + added) & (kFoldRing - 1);
+                fq_count += added;
+                const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;  // a lane's FIFO holds 8 positions
+                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass();
+            }
+        }
+        while (fq_count > 0u) fold_pass();
+    }
     unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
-    while (n < n_end) {
+    while (!DEFER && n < n_end) {
         D3 term;
         bool cont;
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
@@ -938,9 +1052,10 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "wavefront-lds-scene-tiles",
                                       "fast-math-lds-tables-chunk8-park-pack8-sample-split",
                                       "wavefront-scalar-scene", "wavefront-scalar-scene-reject",
-                                      "wavefront-scalar-scene-reject-f32"};
+                                      "wavefront-scalar-scene-reject-f32",
+                                      "fast-math-lds-tables-chunk8-park-pack8-immediate-fold"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -1000,14 +1115,18 @@ static size_t debug_lds_pad() {
 }
 
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
-          bool TRY_PACK8 = false, bool SPLIT = false>
+          bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad();
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
-        if (P.max_bounces >= 0 && P.max_bounces <= 8) {
-            render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT><<<grid, 64, tab, stream>>>(P);
+        if (P.max_bounces >= 0 && P.max_bounces <= 8 && P.scene.n < 256) {  // ids and the identity index in a byte
+            if constexpr (DEFER)
+                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>
+                    <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
+            else
+                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT><<<grid, 64, tab, stream>>>(P);
             return;
         }
     }
@@ -1047,11 +1166,13 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
         if (P.split > 1) {
-            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true>(P, grid * P.split, stream);
+            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
             split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
         } else {
-            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
+            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }
+    } else if (variant == kVariantImmediateFold && n <= kLdsTableMaxSpheres) {
+        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
     } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
         launch_render_depth<MathFast, true, 8, uint8_t, 4, false, false, true>(P, grid, stream);
     } else if (variant == 6 && n <= kLdsTableMaxSpheres) {

@@ -562,9 +562,11 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
 template <class M, int UNROLL, class Scene, typename PushFn>
 __device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const int max_bounces,
                                           D3& org, D3& dir, int& depth, RngStream& rng, D3& term,
-                                          PathCounters& pc, PushFn push, const double* trig_lds = nullptr) {
+                                          PathCounters& pc, PushFn push, const double* trig_lds = nullptr,
+                                          int* hit_id = nullptr) {
     double dis;
     const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+    if (hit_id) *hit_id = id;
     if constexpr (std::is_same<M, MathFast>::value)
         return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push, trig_lds);
     else
@@ -639,6 +641,28 @@ __device__ __forceinline__ D3 path_fold_packed8(const Scene& sc, const D3 term, 
     }
     return L;
 }
+// One queued path end -> its clamped sample term (src/Renderer.cpp:240): the terminal value is the
+// emission row of `term_id` (the identity row, emission +0, for a miss), then the fold.
+template <class Scene>
+__device__ __forceinline__ D3 path_fold_packed8_all(const Scene& sc, const int term_id, const unsigned long long rec) {
+    D3 L = sc.emission(term_id);
+    const unsigned lo = (unsigned)rec, hi = (unsigned)(rec >> 32);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const unsigned word = g ? hi : lo;
+        D3 c[4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = (int)((word >> (8 * k)) & 0xFFu);
+            c[k] = sc.color_kd(id);
+            e[k] = sc.emission(id);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
+    }
+    return L;
+}
+
 // the 64-bit record register of a path that has not bounced yet: identity index in every byte
 __device__ __forceinline__ unsigned long long packed8_empty(int identity) {
     return 0x0101010101010101ull * (unsigned long long)(unsigned)identity;
