@@ -657,6 +657,22 @@ def test_interleaved_bands_reassemble_the_frame(rtm, oracle, scene, w, h, n_big)
         rtm.Renderer(data, mode="repaired", max_bounces=8).render_rows(0, h, band=(2, 2))
 
 
+@pytest.mark.parametrize("n", [255, 256, 257])
+def test_record_packing_boundary(rtm, oracle, n):
+    """Hit ids and the identity index share a byte in the packed records: 255 spheres is the last scene
+    that fits, 256 must take the LDS record stack, 257 the large-scene pipeline — all the same image."""
+    data = rtm.make_stress_scene(n, seed=3)
+    data.width, data.height, data.samples, data.superSamples = 48, 32, 4, 2
+    # pull the camera close so that high-index spheres are hit, too
+    ost, oarr, _ = _oracle_view(oracle, data)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=21, height=32))
+    for v in (0, 1, 2, 9, 13):
+        out, stats = _gpu_image(rtm, data, "repaired", 8, 21, want=("f64",), variant=v)
+        assert np.array_equal(out["f64"], ref), (n, v)
+        assert stats["casts"] == cnt["casts"]
+    assert ref.any()
+
+
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
