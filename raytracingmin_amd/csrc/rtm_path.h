@@ -542,9 +542,12 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
     const int depth0 = depth;
     const RngStream rng0 = rng;
     const PathCounters pc0 = pc;
+    // the hit record is pushed once, after the attempt that counts: a packed record register is not
+    // idempotent under a repeated push (a continuing path pushes exactly (depth before, id))
+    auto no_push = [](int, int) {};
     MathSpec m;
     m.trig_lds = trig_lds;
-    bool cont = path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+    bool cont = path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, no_push);
     if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
         org = org0;
         dir = dir0;
@@ -553,8 +556,9 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
         pc = pc0;
         MathRefI r;
         r.trig_lds = trig_lds;
-        cont = path_shade_with(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
+        cont = path_shade_with(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, no_push);
     }
+    if (cont) push(depth0, id);
     return cont;
 }
 

@@ -564,10 +564,10 @@ def test_edge_case_scenes_vs_oracle(rtm, oracle, name):
     cam = rtm.Camera(rtm.vec3(*origin), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), fov)
     data = rtm.SettingData(width=45, height=27, samples=3, superSamples=2, camera=cam, object=objs)
     ost, oarr, n = _oracle_view(oracle, data)
-    for mode, mb in (("repaired", 8), ("repaired", 3), ("literal", -1)):
+    for mode, mb in (("repaired", 8), ("repaired", 3), ("repaired", 1), ("repaired", 0), ("literal", -1), ("literal", 2)):
         m = oracle.MODE_REPAIRED if mode == "repaired" else oracle.MODE_LITERAL
         ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=17, height=27))
-        for v in (0, 1, 4, 8):
+        for v in (0, 1, 4, 8, 9, 13):
             out, stats = _gpu_image(rtm, data, mode, mb, 17, want=("f64",), variant=v)
             assert np.allclose(out["f64"], ref, rtol=0, atol=PIXEL_TOL, equal_nan=True), (name, mode, mb, v)
             assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"]), (name, mode, mb, v)
