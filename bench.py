@@ -251,6 +251,17 @@ def main():
                         "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        ppath = os.path.join(ROOT, "profiles", "r1", "default_pmc_summary.json")
+        if world == 1 and headline and args.variant == 0 and os.path.exists(ppath):
+            # instruction-issue view of the same kernel (committed PMC pass of this command): a wave64
+            # fp64 VALU instruction occupies its SIMD for 4 cycles (16 fp64 lanes per SIMD per clock)
+            pmc = json.load(open(ppath))
+            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0  # counter is summed over the 8 XCDs
+            line["roofline"]["valu_issue"] = {
+                "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "simds": 1024, "kernel_cycles": cyc,
+                "busy_frac_if_4_cycles_each": pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
+                "active_lanes_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / pmc["SQ_INSTS_VALU"] / 64.0,
+                "source": "profiles/r1/default_pmc_summary.json"}
         if n_spheres > 256 and args.variant in (0, 12):
             # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
             # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
