@@ -236,7 +236,7 @@ def main():
                                    f"{'interleaved 8-row bands' if args.layout == 'bands' else 'row strips'} over "
                                    f"{world} GPU(s) + one gather",
                        "variant": rtm.lib().rtm_variant_name(
-                           args.variant if args.variant else (2 if n_spheres <= 256 else 12)).decode(),
+                           args.variant if args.variant else (2 if n_spheres <= 24 else 14 if n_spheres < 256 else 3 if n_spheres < 512 else 12)).decode(),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
@@ -262,7 +262,7 @@ def main():
                 "busy_frac_if_4_cycles_each": pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
                 "active_lanes_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / pmc["SQ_INSTS_VALU"] / 64.0,
                 "source": "profiles/r1/default_pmc_summary.json"}
-        if n_spheres > 256 and args.variant in (0, 12):
+        if n_spheres >= 512 and args.variant in (0, 12):
             # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
             # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
             tests_per_s = stats["casts"] * n_spheres / (kernel_ms * 1e-3)

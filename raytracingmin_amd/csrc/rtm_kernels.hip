@@ -1053,11 +1053,13 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "fast-math-lds-tables-chunk8-park-pack8-sample-split",
                                       "wavefront-scalar-scene", "wavefront-scalar-scene-reject",
                                       "wavefront-scalar-scene-reject-f32",
-                                      "fast-math-lds-tables-chunk8-park-pack8-immediate-fold"};
+                                      "fast-math-lds-tables-chunk8-park-pack8-immediate-fold",
+                                      "fast-math-global-scene-chunk8-park-pack8"};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
+constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
 const char* variant_name(int v) { return (v >= 0 && v < num_variants()) ? kVariantNames[v] : nullptr; }
 
@@ -1171,6 +1173,13 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         } else {
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }
+    } else if (variant == kVariantGlobalDefer && n < 256) {
+        if (P.split > 1) {
+            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
+            split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
+        } else {
+            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
+        }
     } else if (variant == kVariantImmediateFold && n <= kLdsTableMaxSpheres) {
         launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
     } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
@@ -1268,13 +1277,15 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     double* aux = nullptr;
     if (scalar_scene >= 2) {
         const int n_pad = (P.scene.n + 7) & ~7;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad * 3 + 2) * sizeof(double), stream));
-        RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 2 * sizeof(double), stream));
-        float4* g32 = reinterpret_cast<float4*>(aux + 2 + n_pad);
-        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
+        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad * 3 + 4) * sizeof(double), stream));
+        RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 4 * sizeof(double), stream));
+        float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
+        wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n,
+                                                                      reinterpret_cast<long long*>(aux + 2));
+        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n, n_pad, aux + 4,
                                                                     reinterpret_cast<unsigned long long*>(aux), g32);
         PS.scene.bounds = aux;
-        PS.scene.wprime = aux + 2;
+        PS.scene.wprime = aux + 4;
         PS.scene.geom32 = g32;
     }
     Free free_aux{aux, stream};
@@ -1378,9 +1389,19 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     P.n_tiles = grid;
     P.split = 1;
     P.split_len = P.total_samples;
-    if ((variant == kVariantAuto || variant == kVariantSplit) && n <= (size_t)kLdsTableMaxSpheres) {
-        P.split = choose_split(grid, P.total_samples, opt->device, variant == kVariantSplit);
+    // auto (profiles/r1/variant_thresholds.txt): LDS tables up to 24 spheres (8.5 KB of LDS per wave keeps
+    // 16 waves per CU); global-memory tables up to 511 (the tables no longer cost occupancy); from 512
+    // spheres the wavefront pipeline with its rejection test wins over the monolithic kernel
+    const bool force_split = variant == kVariantSplit;
+    if (variant == kVariantAuto)
+        variant = n <= (size_t)kAutoLdsTableSpheres ? kVariantFastLds : n < 256 ? kVariantGlobalDefer :
+                  n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
+    else if (variant == kVariantSplit)
         variant = kVariantFastLds;
+    // the sample split rides on the packed-record kernels (explicit variant 2 never splits)
+    if (n < 256 && (opt->variant == kVariantAuto || force_split) &&
+        (variant == kVariantFastLds || variant == kVariantGlobalDefer)) {
+        P.split = choose_split(grid, P.total_samples, opt->device, force_split);
         if (P.split > 1) {
             P.split_len = P.total_samples / P.split;
             const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_len) * 192;
@@ -1403,14 +1424,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         RTM_HIP_CHECK(hipEventCreate(&ev1));
         RTM_HIP_CHECK(hipEventRecord(ev0, stream));
     }
-    // auto: scenes beyond the LDS-table size go through the wavefront pipeline
-    const bool wavefront = opt->variant == kVariantWavefront || opt->variant == kVariantWavefrontScalar ||
-                           opt->variant == kVariantWavefrontReject || opt->variant == kVariantWavefrontRejectF32 ||
-                           (opt->variant == kVariantAuto && n > (size_t)kLdsTableMaxSpheres);
+    const bool wavefront = variant == kVariantWavefront || variant == kVariantWavefrontScalar ||
+                           variant == kVariantWavefrontReject || variant == kVariantWavefrontRejectF32;
     if (wavefront) {
-        // auto: scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
-        rc = run_wavefront(P, rows, stream, opt->variant == kVariantWavefront ? 0 : opt->variant == kVariantWavefrontScalar ? 1 :
-                                            opt->variant == kVariantWavefrontReject ? 2 : 3);
+        // scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
+        rc = run_wavefront(P, rows, stream, variant == kVariantWavefront ? 0 : variant == kVariantWavefrontScalar ? 1 :
+                                            variant == kVariantWavefrontReject ? 2 : 3);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, tiles_y, stream);
@@ -1674,7 +1693,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     S.npix = (unsigned)N;
     const int n_pad = ((int)n + 7) & ~7;
     unsigned char* ws = nullptr;
-    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 3 + 2) * 8 + 256;
+    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 3 + 4) * 8 + 256;
     RTM_HIP_CHECK(hipMalloc((void**)&ws, bytes));
     struct Free {
         void* p;
@@ -1692,7 +1711,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     S.hit_id = (int*)take(N * 4);
     S.active[0] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
-    double* aux = (double*)take(((size_t)n_pad * 3 + 2) * 8);
+    double* aux = (double*)take(((size_t)n_pad * 3 + 4) * 8);
     std::vector<double> soa(N * 3);
     std::vector<unsigned> ident(N);
     for (size_t i = 0; i < N; ++i) {
@@ -1708,12 +1727,13 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     RTM_HIP_CHECK(hipMemcpy(S.n_active, counts, sizeof counts, hipMemcpyHostToDevice));
     const unsigned g = (unsigned)((N + 255) / 256);
     if (kind >= 2) {
-        RTM_HIP_CHECK(hipMemset(aux, 0, 16));
-        float4* g32 = reinterpret_cast<float4*>(aux + 2 + n_pad);
-        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, n_pad, aux + 2,
+        RTM_HIP_CHECK(hipMemset(aux, 0, 32));
+        float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
+        wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, reinterpret_cast<long long*>(aux + 2));
+        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, n_pad, aux + 4,
                                                           reinterpret_cast<unsigned long long*>(aux), g32);
         P.scene.bounds = aux;
-        P.scene.wprime = aux + 2;
+        P.scene.wprime = aux + 4;
         P.scene.geom32 = g32;
         if (kind == 3)
             wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256>>>(P, S, 0);

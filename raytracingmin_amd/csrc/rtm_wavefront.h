@@ -148,31 +148,55 @@ __global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, c
         }
 }
 
-// Auxiliary per-sphere data for the rejection test of wf_nearest_scalar_kernel.
+// Auxiliary per-sphere data for the rejection tests.  aux = [R2][r2max][exponent sum][count] then
+// wprime[n_pad] then the float list.  The margins of the tests scale with R2 = max c.c and max r2, so a
+// few spheres far larger or farther than the rest (the wall spheres of a Cornell-style box: r = 1e5
+// around objects of size 1) would make them useless for everything else.  Such OUTLIERS — squared
+// magnitude max(c.c, r2) more than 2^10 above the scene's geometric mean — are left out of R2 / r2max
+// and get w' = +inf (and a zero float centre): their test value is +inf, so they always take the
+// reference arithmetic, which costs a handful of exact tests per ray.
+__global__ __launch_bounds__(256) void wf_scene_scale_kernel(const double4* __restrict__ geom, const int n,
+                                                             long long* __restrict__ acc /* [exponent sum, count] */) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double4 g = geom[i];
+    const double cc = g.x * g.x + g.y * g.y + g.z * g.z;
+    const double m = cc < g.w ? g.w : cc;
+    if (m > 0.0 && m < HUGE_VAL) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)__builtin_amdgcn_frexp_exp(m));
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + 1), 1ull);
+    }
+}
+
 __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __restrict__ geom, const int n, const int n_pad,
                                                            double* __restrict__ wprime, unsigned long long* __restrict__ bounds,
                                                            float4* __restrict__ geom32) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
+    float* q = geom32 ? reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1) : nullptr;
     if (i >= n) {  // padding: a sphere that can never pass the test
         wprime[i] = -HUGE_VAL;
-        if (geom32) {
-            float* q = reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1);
+        if (q) {
             q[0] = q[2] = q[4] = 0.f;
             q[6] = -HUGE_VALF;
         }
         return;
     }
+    const long long* acc = reinterpret_cast<const long long*>(bounds + 2);
+    const long long count = acc[1];
+    const int limit = count > 0 ? (int)(acc[0] / count) + 10 : 0x7FFFFFFF;
     const double4 g = geom[i];
     const double cc = g.x * g.x + g.y * g.y + g.z * g.z;
-    wprime[i] = g.w - cc;
-    if (geom32) {  // spheres 2m, 2m+1 interleaved: cx0 cx1 cy0 cy1 cz0 cz1 w0 w1 (operands of packed fp32 math)
-        float* q = reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1);
-        q[0] = (float)g.x;
-        q[2] = (float)g.y;
-        q[4] = (float)g.z;
-        q[6] = (float)(g.w - cc);
+    const double m = cc < g.w ? g.w : cc;
+    const bool outlier = !(m < HUGE_VAL) || (m > 0.0 && __builtin_amdgcn_frexp_exp(m) > limit);
+    wprime[i] = outlier ? HUGE_VAL : g.w - cc;
+    if (q) {  // spheres 2m, 2m+1 interleaved: cx0 cx1 cy0 cy1 cz0 cz1 w0 w1 (operands of packed fp32 math)
+        q[0] = outlier ? 0.f : (float)g.x;
+        q[2] = outlier ? 0.f : (float)g.y;
+        q[4] = outlier ? 0.f : (float)g.z;
+        q[6] = outlier ? HUGE_VALF : (float)(g.w - cc);
     }
+    if (outlier) return;
     // max over non-negative doubles == max over their bit patterns; NaN / negative values stay out
     if (cc >= 0.0) atomicMax(bounds + 0, (unsigned long long)__double_as_longlong(cc));
     if (g.w >= 0.0) atomicMax(bounds + 1, (unsigned long long)__double_as_longlong(g.w));

@@ -657,6 +657,23 @@ def test_interleaved_bands_reassemble_the_frame(rtm, oracle, scene, w, h, n_big)
         rtm.Renderer(data, mode="repaired", max_bounces=8).render_rows(0, h, band=(2, 2))
 
 
+@pytest.mark.parametrize("n", [25, 60, 511, 512])
+def test_auto_variant_by_scene_size(rtm, oracle, n):
+    """variant 0 picks the kernel by scene size (LDS tables / global tables / wavefront pipeline) and, for
+    a launch this small, the sample split on top: every choice is the reference-loop image."""
+    data = rtm.make_stress_scene(n, seed=8)
+    data.width, data.height, data.samples, data.superSamples = 56, 40, 8, 2
+    ost, oarr, _ = _oracle_view(oracle, data)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=4, height=40))
+    auto, st = _gpu_image(rtm, data, "repaired", 8, 4, want=("f64",), variant=0)
+    plain, _ = _gpu_image(rtm, data, "repaired", 8, 4, want=("f64",), variant=1)
+    assert np.array_equal(auto["f64"], ref) and np.array_equal(plain["f64"], ref)
+    assert (st["casts"], st["draws"]) == (cnt["casts"], cnt["draws"])
+    unl, st = _gpu_image(rtm, data, "repaired", -1, 4, want=("f64",), variant=0)
+    ref_u, cnt_u = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=4, height=40))
+    assert np.array_equal(unl["f64"], ref_u) and st["casts"] == cnt_u["casts"]
+
+
 @pytest.mark.parametrize("n", [255, 256, 257])
 def test_record_packing_boundary(rtm, oracle, n):
     """Hit ids and the identity index share a byte in the packed records: 255 spheres is the last scene
