@@ -112,7 +112,7 @@ int rtm_output_rows(const rtm_options* options);
  * out_f32 is the same value rounded to float (the float3 accumulation buffer); out_u8 is the
  * reference's 8-bit quantisation (src/Renderer.cpp:251-254).
  * Asynchronous on `stream` unless stats != NULL (then it synchronises the stream to read the
- * counters and timing) or the scene has more than 256 spheres (the large-scene pipeline is a host
+ * counters and timing) or the scene has 512 spheres or more (the large-scene pipeline is a host
  * loop of launches that reads the active-pixel count back every iteration).  Hit records of paths deeper than the on-chip levels spill to a pooled
  * buffer (capacity: 992 bounces per path, 65536 such paths per launch); exceeding it is reported as
  * RTM_ERR_UNSUPPORTED, which — like the counters — can only be observed when stats != NULL.

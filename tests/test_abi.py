@@ -91,3 +91,14 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in src and "cpu_ref" not in src and "rtmo_" not in src, f
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() compiles everything and imports the package
+    (it asserts the ABI version, so this catches a bump that forgot it)."""
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.build()
