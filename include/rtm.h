@@ -114,7 +114,7 @@ int rtm_output_rows(const rtm_options* options);
  * Asynchronous on `stream` unless stats != NULL (then it synchronises the stream to read the
  * counters and timing) or the scene has 512 spheres or more (the large-scene pipeline is a host
  * loop of launches that reads the active-pixel count back every iteration).  Hit records of paths deeper than the on-chip levels spill to a pooled
- * buffer (capacity: 992 bounces per path, 65536 such paths per launch); exceeding it is reported as
+ * buffer (capacity: 976 bounces per path); exceeding it is reported as
  * RTM_ERR_UNSUPPORTED, which — like the counters — can only be observed when stats != NULL.
  * Scene arrays are HOST pointers (tiny for shipped scenes) unless spheres_on_device != 0. */
 int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,

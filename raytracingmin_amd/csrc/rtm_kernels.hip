@@ -200,13 +200,20 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //           the term in LDS, and every owner then adds its terms to its accumulator in the order its
 //           paths ended (a per-lane FIFO of ring positions keeps that order) — the accumulation order
 //           of src/Renderer.cpp:241-242 is untouched.
+//   PACKL   (with DEFER) packed records for paths of ANY depth (max_bounces < 0 or > 8): level d in byte
+//           d & 7 of word d >> 3 — word 0 in a register, word 1 in LDS per lane, levels from 16 up (about
+//           kd^16 of the paths) in the pooled global stack.  A queue entry carries both words and the pool
+//           slot; a lane that queues a path deeper than 16 forces a pass, so its slot is free again
+//           before its next path can reach level 16.
 constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
 constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
+constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
 
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
-          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false>
+          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
-    static_assert(!DEFER || (PACK8 && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
+    static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
+    static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
@@ -221,7 +228,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* fq_out = reinterpret_cast<double*>(fq_in + kFoldRing);
     unsigned long long* fq_fifo = reinterpret_cast<unsigned long long*>(fq_out + 3 * 64);
     unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
+    unsigned long long* fq_in1 = reinterpret_cast<unsigned long long*>(fq_pend + 64);  // PACKL: word 1 of the entries
+    unsigned long long* rec_w1 = fq_in1 + kFoldRing;                                   // PACKL: word 1 of the lanes
     if constexpr (DEFER) fq_pend[lane] = 0u;
+    if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
     if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
@@ -268,6 +278,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     PathCounters pc = {0, 0, 0};
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
+    if constexpr (PACKL) {
+        if (P.pool) stack.slot = (int)(blockIdx.x * 64u + (unsigned)lane);  // one pooled stack per lane, no allocator
+    }
     D3 acc = d3(0, 0, 0);
 
     // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
@@ -293,10 +306,20 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     unsigned long long recq = packed8_empty(P.scene.n);  // PACK8 records, most recent bounce in the low byte
     auto push = [&](int d, int id) {
-        if constexpr (PACK8)
+        if constexpr (PACK8) {
             recq = (recq << 8) | (unsigned long long)(unsigned)id;
-        else
+        } else if constexpr (PACKL) {
+            // the byte still holds the identity index: xor turns it into id
+            const unsigned long long flip = (unsigned long long)((unsigned)id ^ (unsigned)P.scene.n) << (8 * (d & 7));
+            if (d < 8)
+                recq ^= flip;
+            else if (d < 16)
+                rec_w1[lane] ^= flip;
+            else
+                stack.push(d - 16, id);  // LDS_D == 0: straight to the pooled stack
+        } else {
             stack.push(d, id);
+        }
     };
     auto pop = [&](int d) -> int { return stack.pop(d); };
     const bool pow2 = P.inv_s != 0.0;  // wave-uniform
@@ -306,8 +329,15 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     auto fold_pass = [&]() {
         const unsigned m = fq_count < 64u ? fq_count : 64u;
         if ((unsigned)lane < m) {
-            const uint4 e = fq_in[(fq_head + (unsigned)lane) & (kFoldRing - 1)];
-            const D3 L = path_fold_packed8_all(sc, (int)e.z, (unsigned long long)e.x | ((unsigned long long)e.y << 32));
+            const unsigned at = (fq_head + (unsigned)lane) & (kFoldRing - 1);
+            const uint4 e = fq_in[at];
+            const unsigned long long w0 = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+            D3 L;
+            if constexpr (PACKL)
+                L = path_fold_packed16(sc, (int)(e.z & 0xFFu), (int)(e.z >> 8), w0, fq_in1[at],
+                                       P.pool + (size_t)e.w * kPoolLevels);
+            else
+                L = path_fold_packed8_all(sc, (int)e.z, w0);
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;  // :240
             const D3 add = clamp01_d3(cal);
             fq_out[0 * 64 + lane] = add.x;
@@ -350,20 +380,28 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if (n < n_end) {
                 D3 term;
                 int hit_id;
-                const bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push,
-                                                       trig, &hit_id);
+                bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push,
+                                                 trig, &hit_id);
+                if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
                 if (!cont) {
                     // queue this path end: ring position = tail + rank among the lanes ending now
                     const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
                     const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                    fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32),
-                                       (unsigned)(hit_id < 0 ? P.scene.n : hit_id), 0u};
+                    const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
+                    if constexpr (PACKL) {
+                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
+                                           (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
+                        fq_in1[pos] = rec_w1[lane];
+                        if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
+                    } else {
+                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
+                    }
                     const unsigned pend = fq_pend[lane] + 1u;
                     fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
                     fq_pend[lane] = pend;
-                    fifo_full = pend >= 8u;
+                    fifo_full = pend >= 8u || (PACKL && depth > 16);  // pooled levels must be folded before reuse
                     ended = true;
                     // next sample of this pixel (src/Renderer.cpp:236-239)
                     ++n;
@@ -1033,8 +1071,8 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
         set_last_error("image, sample or scene count exceeds 32-bit indexing");
         return RTM_ERR_UNSUPPORTED;
     }
-    if (opt->max_bounces > 32 + kPoolLevels) {
-        set_last_error("max_bounces exceeds the hit-record capacity (992); use -1 for unlimited");
+    if (opt->max_bounces > 16 + kPoolLevels) {
+        set_last_error("max_bounces exceeds the hit-record capacity (976); use -1 for unlimited");
         return RTM_ERR_UNSUPPORTED;
     }
     if (opt->variant < 0 || opt->variant >= num_variants()) {
@@ -1129,6 +1167,13 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
                     <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
             else
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT><<<grid, 64, tab, stream>>>(P);
+            return;
+        }
+    }
+    if constexpr (DEFER && sizeof(RecT) == 1) {
+        if (P.scene.n < 256) {  // any depth: packed records + pooled stack, deferred fold
+            render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
+                <<<grid, 64, tab + kFoldQueueBytesL, stream>>>(P);
             return;
         }
     }
@@ -1363,24 +1408,14 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     P.out32 = out32;
     P.out8 = out8;
     P.counters = ds.counters;
-    // deep-path record pool: 65536 slots x 960 records (60 MiB u8 / 240 MiB u32), stream-ordered
     unsigned char* pool = nullptr;
-    if (needs_pool(P)) {
-        const size_t rec_bytes = (n <= 256) ? 1 : 4;
-        P.pool_slots = 65536;
-        const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&pool, pool_bytes + 64, stream));
-        P.pool = pool;
-        P.pool_next = reinterpret_cast<unsigned*>(pool + pool_bytes);
-        RTM_HIP_CHECK(hipMemsetAsync(P.pool_next, 0, sizeof(unsigned), stream));
-    }
     struct PoolFree {
         unsigned char* p;
         hipStream_t s;
         ~PoolFree() {
             if (p) (void)hipFreeAsync(p, s);
         }
-    } pool_free{pool, stream};
+    };
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
     // sample split (default kernel only): per-sample terms of waves 1.. in a stream-ordered buffer
@@ -1411,6 +1446,22 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         }
     }
     PoolFree split_free{reinterpret_cast<unsigned char*>(split_ws), stream};
+    // deep-path record pool, stream-ordered.  Kernels with an LDS record stack take a slot only for the
+    // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
+    // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
+    const bool packl = n < 256 && !(P.max_bounces >= 0 && P.max_bounces <= 8) &&
+                       (variant == kVariantFastLds || variant == kVariantGlobalDefer);
+    if (needs_pool(P)) {
+        const size_t rec_bytes = (n <= 256) ? 1 : 4;
+        P.pool_slots = packl ? grid * P.split * 64u : 65536u;
+        const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
+        RTM_HIP_CHECK(hipMallocAsync((void**)&pool, pool_bytes + 64, stream));
+        P.pool = pool;
+        P.pool_next = reinterpret_cast<unsigned*>(pool + pool_bytes);
+        RTM_HIP_CHECK(hipMemsetAsync(P.pool_next, 0, sizeof(unsigned), stream));
+    }
+    PoolFree pool_free{pool, stream};
+
     unsigned long long* stamps = nullptr;
     if (opt->variant == 7) {
         RTM_HIP_CHECK(hipMalloc((void**)&stamps, (size_t)grid * 4 * sizeof(unsigned long long)));
@@ -1462,8 +1513,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         stats->draws = c[2];
         stats->kernel_ms = ms;
         if (c[3]) {
-            set_last_error("a path ran deeper than the hit-record capacity (LDS levels + 960 pooled levels, "
-                           "65536 pooled paths per launch)");
+            set_last_error("a path ran deeper than the hit-record capacity (16-64 on-chip levels + 960 pooled levels)");
             return RTM_ERR_UNSUPPORTED;
         }
     }

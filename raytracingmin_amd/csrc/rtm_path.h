@@ -667,6 +667,41 @@ __device__ __forceinline__ D3 path_fold_packed8_all(const Scene& sc, const int t
     return L;
 }
 
+// The same for paths of any depth (PACKL records): level d sits in byte d & 7 of word d >> 3 (w0: levels
+// 0-7, w1: 8-15), levels from 16 up in this path's pooled stack `deep` (deep[0] = level 16).  Bytes a
+// path never reached hold the identity row's index, so whole words are folded without compares;
+// deepest level first, like the recursion unwinds.
+template <class Scene>
+__device__ __forceinline__ D3 path_fold_packed16(const Scene& sc, const int term_id, const int depth,
+                                                 const unsigned long long w0, const unsigned long long w1,
+                                                 const unsigned char* deep) {
+    D3 L = sc.emission(term_id);
+    if (__builtin_amdgcn_ballot_w64(depth > 16) != 0) {  // rare: P(depth > 16) ~ kd^16
+        for (int d = depth - 1; d >= 16; --d) {
+            const int id = (int)deep[d - 16];
+            L = sc.color_kd(id) * L + sc.emission(id);
+        }
+    }
+    auto word = [&](const unsigned long long w) {
+        const unsigned half[2] = {(unsigned)(w >> 32), (unsigned)w};  // levels 7..4, then 3..0
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            D3 c[4], e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int id = (int)((half[g] >> (8 * (3 - k))) & 0xFFu);
+                c[k] = sc.color_kd(id);
+                e[k] = sc.emission(id);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) L = c[k] * L + e[k];
+        }
+    };
+    if (__builtin_amdgcn_ballot_w64(depth > 8) != 0) word(w1);
+    word(w0);
+    return L;
+}
+
 // the 64-bit record register of a path that has not bounced yet: identity index in every byte
 __device__ __forceinline__ unsigned long long packed8_empty(int identity) {
     return 0x0101010101010101ull * (unsigned long long)(unsigned)identity;
