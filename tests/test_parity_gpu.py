@@ -683,11 +683,17 @@ def test_record_packing_boundary(rtm, oracle, n):
     # pull the camera close so that high-index spheres are hit, too
     ost, oarr, _ = _oracle_view(oracle, data)
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=21, height=32))
-    for v in (0, 1, 2, 9, 13):
+    for v in (0, 1, 2, 9, 13, 14):
         out, stats = _gpu_image(rtm, data, "repaired", 8, 21, want=("f64",), variant=v)
         assert np.array_equal(out["f64"], ref), (n, v)
         assert stats["casts"] == cnt["casts"]
     assert ref.any()
+    # any depth: records packed by position, deep levels in the pooled stack
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=21, height=32))
+    for v in (0, 2, 9, 14, 13):
+        out, stats = _gpu_image(rtm, data, "repaired", -1, 21, want=("f64",), variant=v)
+        assert np.array_equal(out["f64"], ref), (n, v, "unlimited")
+        assert stats["casts"] == cnt["casts"]
 
 
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
