@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __rest
 //    REJECTED; for that decision the reference's 16 non-fused operations are not needed.  With
 //    P = c - o:  D4 = (P.d)^2 - P.P + r2 = (c.d - o.d)^2 + (r2 - c.c) + 2 c.o - o.o, which is 8 FMAs per
 //    sphere from (cx, cy, cz, w' = r2 - c.c) and per-ray constants.  Both this value and the
-//    reference's are within  72 u (1 + d.d)(max c.c + o.o + max r2)  of the exact discriminant
+//    reference's are within  27 u (1 + d.d)(max c.c + o.o + max r2)  of the exact discriminant
 //    (u = 2^-53; standard dot-product bounds), so a sphere whose fused value is below
 //    -margin, margin = 2048 u (...), has a negative reference discriminant and cannot be hit.  Any
 //    other chunk runs the reference's arithmetic (sphere_chunk_g), which alone decides hits: the
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderPa
 //   D4 = (c.d)^2 + c.e + w' + k,   e = 2o - 2(o.d)d,  k = (o.d)^2 - o.o   (per-ray, computed in fp64)
 // = 1 mul + 6 fma + 1 add in fp32.  With u = 2^-24, rounding every input to float and every operation
 // once gives (Higham's gamma_n bounds; sum |c_i||x_i| <= R |x|_1, R^2 = max c.c):
-//   |D4_f32 - D4| <= u [ 11.4 R^2 d.d + 7.3 R |e|_1 + 6.3 |k| + 3.2 (R^2 + max r2) ]
+//   |D4_f32 - D4| <= u [ 11.7 R^2 d.d + 7.2 R |e|_1 + 6.1 |k| + 6.1 (R^2 + max r2) ]
 // plus underflow (<= 17 x 2^-126 x max(1, |d|, |e|, 2R|d|)) and the fp64-level terms of
 // wf_nearest_scalar_kernel.  The kernel uses 16 u (...) + 2^-110 (1 + d.d + |e|_1 + R^2) + the fp64
 // margin, rounded up; a chunk none of whose spheres reaches -margin in any lane is skipped, and in any
