@@ -179,12 +179,14 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //   LDS_TAB scene tables (centres + materials) copied to LDS for the per-lane look-ups
 //   UNROLL  spheres whose geometry is fetched together (wave-uniform loads)
 //   RecT    hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged in LDS per lane
-// Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat n*8 doubles][records].
+// Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat (n+1)*8][norm n*2] (LDS_TAB), [camera 10]
+// [sincos constants 16][accumulator + primary direction 6 x 64] (PARK), then the record stack
+// [LDS_D][64] or the fold queue (DEFER).
 //   PARK    the pixel accumulator and the cached primary direction live in LDS ([component][lane]),
 //           not in VGPRs: they are touched once per sample, and the 12 registers they would pin
 //           are what the unrolled sphere chunk needs to stay under 128 VGPRs without scratch spills
 //   STAMP   diagnostic build: s_memtime around the three segments of an iteration (never timed itself)
-//   PACK8   max_bounces <= 8 and n <= 256: hit records packed in a 64-bit register, no LDS stack
+//   PACK8   max_bounces <= 8 and n < 256: hit records packed in a 64-bit register, no LDS stack
 //   SPLIT   P.split waves per tile, each tracing a contiguous range of the pixel's samples.  Wave 0
 //           accumulates as usual and leaves its accumulator in P.partial; the others store every
 //           sample's term (src/Renderer.cpp:240-242, after the clamp) to P.contrib, and
