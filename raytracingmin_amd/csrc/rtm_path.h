@@ -410,9 +410,45 @@ __device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int 
         hit_object = accept ? i0 + k : hit_object;
     }
 }
+// spheres whose geometry is fetched together inside a chunk (profiles/r1: 7 at once 202.7 ms, 4: 195.6,
+// 3: 194.5, 2: 194.2 ms on the same box; SGPR spills 44 -> 10)
+constexpr int kGeomPhase = 2;
 template <class M, int K, class Scene, bool EARLY_OUT = false>
 __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
                                              double& dis, int& hit_object) {
+    constexpr int PH = kGeomPhase;
+    if constexpr (K > PH && !EARLY_OUT) {
+        // The geometry of a chunk arrives by scalar loads, 8 SGPRs per sphere; fetching all K spheres at
+        // once pins 8K SGPRs across the discriminants and makes hipcc spill the kernel's long-lived
+        // scalars to VGPR lanes (v_writelane / v_readlane in the hot loop).  Phases of PH spheres keep
+        // the batch structure of the rest (K independent chains into ONE sqrt guard and K selects).
+        double b[K], D4[K], sq[K];
+#pragma unroll
+        for (int k0 = 0; k0 < K; k0 += PH) {
+            double4 g[PH];
+#pragma unroll
+            for (int k = 0; k < PH; ++k)
+                if (k0 + k < K) g[k] = sc.geom_uniform(i0 + k0 + k);
+#pragma unroll
+            for (int k = 0; k < PH; ++k)
+                if (k0 + k < K) {
+                    const D3 p_o = d3(g[k].x - org.x, g[k].y - org.y, g[k].z - org.z);  // src/SettingData.cpp:198
+                    b[k0 + k] = dot(p_o, dir);                                          // :199
+                    D4[k0 + k] = b[k0 + k] * b[k0 + k] - dot(p_o, p_o) + g[k].w;        // :200
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        M::template sqrt64_batch<K>(D4, sq);  // :205 (D4 < 0 gives NaN: no hit)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
+            const double t = (t1 > 0.001) ? t1 : t2;
+            const bool accept = (t < dis) && !(t < (double)1e-5f);
+            dis = accept ? t : dis;
+            hit_object = accept ? i0 + k : hit_object;
+        }
+        return;
+    }
     double4 g[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) g[k] = sc.geom_uniform(i0 + k);
