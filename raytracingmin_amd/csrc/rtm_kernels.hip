@@ -1215,8 +1215,13 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
     } else if (variant == kVariantFastLds) {
         if (P.split > 1) {
-            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
+            if (n < 8)
+                launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
+            else
+                launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
             split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
+        } else if (n < 8) {  // no full chunk of 8: the instantiation without the chunk loop
+            launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         } else {
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }

@@ -25,6 +25,10 @@ struct MathRef {
 #pragma unroll
         for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
     }
+    template <int K>
+    static __device__ __forceinline__ void sqrt64_batch_hit(const double (&x)[K], double (&out)[K]) {
+        sqrt64_batch<K>(x, out);
+    }
 };
 
 // MathFast: the same instruction sequences with the range-scaling steps hoisted into one
@@ -69,6 +73,45 @@ struct MathFast {
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < K; ++k) ok = ok && sqrt_fast_ok(x[k]);
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
+            return;
+        }
+        double y[K], s0[K], h0[K], r0[K], s1[K], h1[K], d0[K], s2[K], d1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) y[k] = __builtin_amdgcn_rsq(x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { s0[k] = x[k] * y[k]; h0[k] = 0.5 * y[k]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) r0[k] = __builtin_fma(-h0[k], s0[k], 0.5);
+#pragma unroll
+        for (int k = 0; k < K; ++k) { s1[k] = __builtin_fma(s0[k], r0[k], s0[k]); h1[k] = __builtin_fma(h0[k], r0[k], h0[k]); }
+#pragma unroll
+        for (int k = 0; k < K; ++k) d0[k] = __builtin_fma(-s1[k], s1[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) s2[k] = __builtin_fma(d0[k], h1[k], s1[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) d1[k] = __builtin_fma(-s2[k], s2[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = __builtin_fma(d1[k], h1[k], s2[k]);
+    }
+    // The square roots of a chunk of DISCRIMINANTS (src/SettingData.cpp:205), for the nearest-hit search
+    // only.  There the guard can be one unsigned compare per value — "not in [+0, 2^-767)" — because
+    // every other operand the unscaled sequence gets wrong yields the same decision as the reference:
+    //   D4 < 0      rsq gives NaN, t is NaN, nothing is accepted (the reference returns false);
+    //   D4 = +inf   the sequence gives NaN where sqrt gives +inf; with sq = +inf, t1 = b - inf is -inf or
+    //               NaN, so t = t2 = b + inf is +inf or NaN and "t < dis" is false either way;
+    //   D4 = NaN    NaN both ways;
+    //   D4 = -0     cannot occur: D4 = (b*b - p.p) + r2 with r2 = (double)(r*r) >= +0, and x + (+0 or a
+    //               positive number) is never -0.
+    // +0, subnormals and tiny normals are the cases that need ocml's pre-scaling (a tangent ray with
+    // D4 = +0 has a real hit at t = b).
+    template <int K>
+    static __device__ __forceinline__ void sqrt64_batch_hit(const double (&x)[K], double (&out)[K]) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ok = ok && ((unsigned)__double2hiint(x[k]) >= 0x10000000u);
         if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
@@ -400,7 +443,7 @@ __device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int 
         }
         return;
     }
-    M::template sqrt64_batch<K>(D4, sq);                           // :205 (D4 < 0 gives NaN: no hit)
+    M::template sqrt64_batch_hit<K>(D4, sq);                       // :205 (D4 < 0 gives NaN: no hit)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
@@ -438,7 +481,10 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        M::template sqrt64_batch<K>(D4, sq);  // :205 (D4 < 0 gives NaN: no hit)
+        if constexpr (K >= 8)
+            M::template sqrt64_batch<K>(D4, sq);  // :205 (D4 < 0 gives NaN: no hit)
+        else
+            M::template sqrt64_batch_hit<K>(D4, sq);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
@@ -462,7 +508,7 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
     int hit_object = -1;
     dis = DBL_MAX;
     const int n = sc.n();
-    if constexpr (UNROLL <= 1) {
+    if constexpr (UNROLL == 0 || UNROLL == 1) {
         for (int i = 0; i < n; ++i) {
             const double4 g = sc.geom_uniform(i);
             double t;
@@ -472,9 +518,14 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
             }
         }
     } else {
-        static_assert(UNROLL == 8 || UNROLL == 4, "chunks of 8 or 4 plus an exact tail");
+        // UNROLL < 0: the caller guarantees n < -UNROLL, so there is no full chunk and the loop is not even
+        // compiled (it is what sets the kernel's register high-water mark)
+        constexpr int U = UNROLL < 0 ? -UNROLL : UNROLL;
+        static_assert(U == 8 || U == 4, "chunks of 8 or 4 plus an exact tail");
         int i0 = 0;
-        for (; i0 + UNROLL <= n; i0 += UNROLL) sphere_chunk<M, UNROLL>(sc, i0, org, dir, dis, hit_object);
+        if constexpr (UNROLL > 0) {
+            for (; i0 + U <= n; i0 += U) sphere_chunk<M, U>(sc, i0, org, dir, dis, hit_object);
+        }
         switch (n - i0) {  // wave-uniform: exactly one tail chunk, sized to the remainder
             case 1: sphere_chunk<M, 1>(sc, i0, org, dir, dis, hit_object); break;
             case 2: sphere_chunk<M, 2>(sc, i0, org, dir, dis, hit_object); break;
