@@ -754,3 +754,13 @@ def test_headline_config_strip_vs_oracle(rtm, oracle):
         .render_rows_device(want=("f64",))
     assert np.array_equal(ref["f64"].cpu().numpy().view(np.uint64), img.view(np.uint64))
     assert {k: ref_stats[k] for k in ("casts", "bounces", "draws")} == {k: stats[k] for k in ("casts", "bounces", "draws")}
+    # what bench.py --gpus 8 runs per rank — interleaved 8-row bands, each a one-round launch that gets
+    # the sample split — reassembles to the same frame, and the parts' counters add up
+    from raytracingmin_amd.distributed import band_row_index
+    got = np.empty_like(img)
+    casts = 0
+    for rank in range(8):
+        part, st = r.render_rows_device(0, 1080, want=("f64",), band=(8, rank))
+        got[band_row_index(0, 1080, 8, rank)] = part["f64"].cpu().numpy()
+        casts += st["casts"]
+    assert np.array_equal(got.view(np.uint64), img.view(np.uint64)) and casts == stats["casts"]
