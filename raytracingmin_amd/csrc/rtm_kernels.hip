@@ -59,10 +59,11 @@ struct RenderParams {
     unsigned* __restrict__ pool_next;       // bump allocator
     unsigned pool_slots;
     unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
-    // sample split (SPLIT kernels): `split` waves per tile, wave f traces samples [f*split_len, (f+1)*split_len)
-    unsigned n_tiles, split, split_len;
-    double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_len samples
-    double* __restrict__ contrib;  // [tile][total_samples - split_len][3][64]: per-sample terms of waves 1..
+    // sample split (SPLIT kernels): `split` waves per tile; wave 0 traces samples [0, split_head), wave f >= 1
+    // samples [split_head + (f-1)*split_len, split_head + f*split_len)
+    unsigned n_tiles, split, split_head, split_len;
+    double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_head samples
+    double* __restrict__ contrib;  // [tile][total_samples - split_head][3][64]: per-sample terms of waves 1..
 };
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
     const unsigned split_f = SPLIT ? blockIdx.x / P.n_tiles : 0u;
-    const unsigned n_first = SPLIT ? split_f * P.split_len : 0u;
-    const unsigned n_end = SPLIT ? n_first + P.split_len : P.total_samples;
+    const unsigned n_first = (SPLIT && split_f != 0) ? P.split_head + (split_f - 1u) * P.split_len : 0u;
+    const unsigned n_end = SPLIT ? (split_f != 0 ? n_first + P.split_len : P.split_head) : P.total_samples;
     unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
     int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
     const int sub_first = (int)(n_first / (unsigned)P.S);
@@ -356,8 +357,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if (mine) {
                 if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
                     const unsigned tile = blockIdx.x % P.n_tiles;
-                    double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_len) * 192;
-                    const unsigned o = ((n - pend) - P.split_len) * 192u + (unsigned)lane;  // n - pend: this entry's sample
+                    double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_head) * 192;
+                    const unsigned o = ((n - pend) - P.split_head) * 192u + (unsigned)lane;  // n - pend: this entry's sample
                     row[o] = fq_out[0 * 64 + rel];
                     row[o + 64] = fq_out[1 * 64 + rel];
                     row[o + 128] = fq_out[2 * 64 + rel];
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             const D3 add = clamp01_d3(cal);
             if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
                 const unsigned tile = blockIdx.x % P.n_tiles;
-                double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_len) * 192;
-                const unsigned o = (n - P.split_len) * 192u + (unsigned)lane;
+                double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_head) * 192;
+                const unsigned o = (n - P.split_head) * 192u + (unsigned)lane;
                 row[o] = add.x;
                 row[o + 64] = add.y;
                 row[o + 128] = add.z;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 }
 
-// Second half of a SPLIT render: image[pixel] = (((partial + term[split_len]) + term[split_len+1]) + ...),
+// Second half of a SPLIT render: image[pixel] = (((partial + term[split_head]) + term[split_head+1]) + ...),
 // the accumulation order of src/Renderer.cpp:241-242.  One wave per tile; the loads are 512-byte rows
 // and independent of the adds, so the kernel streams P.contrib at HBM rate (1536 B per pixel sample).
 __global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P) {
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P
     const unsigned tile = blockIdx.x;
     const double* part = P.partial + (size_t)tile * 192 + lane;
     D3 acc = d3(part[0], part[64], part[128]);
-    const unsigned ns = P.total_samples - P.split_len;
+    const unsigned ns = P.total_samples - P.split_head;
     const double* row = P.contrib + (size_t)tile * ns * 192 + lane;
     unsigned m = 0;
     for (; m + 8 <= ns; m += 8) {
@@ -1430,7 +1431,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     double* split_ws = nullptr;
     P.n_tiles = grid;
     P.split = 1;
-    P.split_len = P.total_samples;
+    P.split_len = P.split_head = P.total_samples;
     // auto (profiles/r1/variant_thresholds.txt): LDS tables up to 24 spheres (8.5 KB of LDS per wave keeps
     // 16 waves per CU); global-memory tables up to 511 (the tables no longer cost occupancy); from 512
     // spheres the wavefront pipeline with its rejection test wins over the monolithic kernel
@@ -1445,8 +1446,14 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         (variant == kVariantFastLds || variant == kVariantGlobalDefer)) {
         P.split = choose_split(grid, P.total_samples, opt->device, force_split);
         if (P.split > 1) {
+            // choose_split gives the granularity (1/f of a pixel's samples per small wave).  Wave 0 takes half
+            // of the samples when f >= 4: its terms never leave the chip, which halves the term traffic
+            // (7/8 -> 1/2 of the samples at f = 8), and it starts in the first round, so the small waves
+            // still set the tail.
             P.split_len = P.total_samples / P.split;
-            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_len) * 192;
+            P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
+            P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
+            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 192;
             RTM_HIP_CHECK(hipMallocAsync((void**)&split_ws, (part + terms) * sizeof(double), stream));
             P.partial = split_ws;
             P.contrib = split_ws + part;
