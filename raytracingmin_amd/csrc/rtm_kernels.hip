@@ -1247,29 +1247,32 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     }
 }
 
-// Sample split of the default kernel.  A launch with fewer tiles than a few rounds of resident waves
+// Sample split of the default kernel.  A launch with fewer tiles than about six rounds of resident waves
 // (256 CUs x 4 SIMDs x 4 waves on MI355X) ends with SIMDs idling while the costliest tiles finish:
-// measured max/mean per-tile cost on the Cornell box is ~1.27 (profiles/r1/strip_balance.txt).  Such
-// launches get `split` waves per tile; the smallest power of two that yields >= 6 rounds, while the
-// term buffer (1536 B per pixel-tile sample beyond wave 0's) stays within the budget.
+// measured max/mean per-tile cost on the Cornell box is ~1.27 (profiles/r1/strip_balance.txt).  Such a
+// launch is cut finer: the result is the GRANULARITY g — small waves trace 1/g of a pixel's samples, and
+// (render_device) wave 0 of a tile takes half of them when g >= 4.  1/16 is the measured sweet spot for
+// one-eighth to one-half of a 1080p frame (profiles/r1/band_split_sweep_final.json); short sample counts
+// and the term buffer (1536 B per tile-sample that is not wave 0's, at most 24 GiB) cap it.
 static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
     static const long env = [] {
-        const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, k = k waves per tile
+        const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, g = that granularity
         return e ? std::strtol(e, nullptr, 10) : 0L;
     }();
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const unsigned slots = (unsigned)cus * 16u;
-    auto fits = [&](unsigned f) {
-        if (f < 2 || total_samples % f != 0 || total_samples / f < 8) return false;
-        const double bytes = (double)n_tiles * (double)(total_samples - total_samples / f) * 1536.0;
-        return bytes <= 24.0 * 1024 * 1024 * 1024 && (double)(total_samples - total_samples / f) * 1536.0 < 4.0e9;
+    auto fits = [&](unsigned g) {
+        if (g < 2 || total_samples % g != 0 || total_samples / g < 8) return false;
+        const unsigned head = g >= 4 ? total_samples / 2 : total_samples / g;
+        const double per_tile = (double)(total_samples - head) * 1536.0;
+        return (double)n_tiles * per_tile <= 24.0 * 1024 * 1024 * 1024 && per_tile < 4.0e9;
     };
     if (env > 0) return (env > 1 && fits((unsigned)env)) ? (unsigned)env : 1u;
-    unsigned f = 1;
-    while ((unsigned long long)n_tiles * f < 6ull * slots && fits(f * 2)) f *= 2;
-    if (forced && f == 1 && fits(2)) f = 2;
-    return f;
+    if (!forced && (unsigned long long)n_tiles >= 6ull * slots) return 1u;
+    unsigned g = 1;
+    while (g < 16u && fits(g * 2)) g *= 2;
+    return g;
 }
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
