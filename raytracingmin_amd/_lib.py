@@ -59,6 +59,7 @@ SIGNATURES = {
     "rtm_last_error_detail": (C.c_char_p, []),
     "rtm_device_count": (C.c_int, [_P(C.c_int)]),
     "rtm_output_rows": (C.c_int, [_P(rtm_options)]),
+    "rtm_release_scratch": (C.c_int, [C.c_int]),
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
     "rtm_render_device": (C.c_int, [_P(rtm_settings), C.c_void_p, C.c_size_t, C.c_int,

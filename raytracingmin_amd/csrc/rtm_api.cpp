@@ -37,6 +37,7 @@ const char* rtm_last_error_detail(void) { return rtm::last_error(); }
 int rtm_device_count(int* count) { RTM_GUARD(rtm::device_count(count)) }
 int rtm_num_variants(void) { return rtm::num_variants(); }
 int rtm_output_rows(const rtm_options* options) { return options ? rtm::output_rows(options) : 0; }
+int rtm_release_scratch(int device) { RTM_GUARD(rtm::release_scratch(device)) }
 const char* rtm_variant_name(int variant) { return rtm::variant_name(variant); }
 
 int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,

@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1247,6 +1249,62 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     }
 }
 
+// Large work buffers (the sample split's term buffer, the pooled record stacks, the wavefront state)
+// are kept per (device, stream, role) and grown on demand: calls on one stream are ordered by the stream,
+// so the buffer of the previous call can be reused without any wait, and different streams get
+// different buffers.  Allocating them stream-ordered per call instead let the pool hand out FRESH
+// multi-GB blocks whenever the host ran ahead of the GPU (a 2.4 GB first touch per step: 10 -> 40 ms
+// for a 512x512 unlimited-depth frame, intermittently).  release_scratch() frees them.
+namespace {
+struct ScratchKey {
+    int device;
+    hipStream_t stream;
+    int role;
+    bool operator<(const ScratchKey& o) const {
+        return std::tie(device, stream, role) < std::tie(o.device, o.stream, o.role);
+    }
+};
+struct ScratchBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+std::mutex g_scratch_mu;
+std::map<ScratchKey, ScratchBuf> g_scratch;
+}  // namespace
+enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchWavefrontAux = 3 };
+
+static int scratch_acquire(int device, hipStream_t stream, int role, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    ScratchBuf& b = g_scratch[ScratchKey{device, stream, role}];
+    if (b.bytes < bytes) {
+        if (b.ptr) {  // the previous, smaller buffer may still be in use by queued work of this stream
+            RTM_HIP_CHECK(hipStreamSynchronize(stream));
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+        RTM_HIP_CHECK(hipMalloc(&b.ptr, bytes));
+        b.bytes = bytes;
+    }
+    *out = b.ptr;
+    return RTM_OK;
+}
+
+int release_scratch(int device) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+        if (device < 0 || it->first.device == device) {
+            (void)hipSetDevice(it->first.device);
+            (void)hipDeviceSynchronize();
+            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            it = g_scratch.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return RTM_OK;
+}
+
 // Sample split of the default kernel.  A launch with fewer tiles than about six rounds of resident waves
 // (256 CUs x 4 SIMDs x 4 waves on MI355X) ends with SIMDs idling while the costliest tiles finish:
 // measured max/mean per-tile cost on the Cornell box is ~1.27 (profiles/r1/strip_balance.txt).  Such a
@@ -1283,7 +1341,7 @@ static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, 
     wf_nearest_kernel<MathFast, TILE, K, R><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
 }
 
-static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, int scalar_scene) {
+static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, int scalar_scene, int device) {
     // (TILE, K, R) = (512 spheres per LDS tile, 4 per chunk, 1 ray per lane): profiles/r1/wf_tune.txt —
     // smaller chunks or 2-4 rays per lane (fewer LDS reads per ray, fewer waves) were 0-50 % slower
     WfState S;
@@ -1300,14 +1358,8 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     const size_t N = S.npix;
     const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256;
     unsigned char* ws = nullptr;
-    RTM_HIP_CHECK(hipMallocAsync((void**)&ws, bytes, stream));
-    struct Free {
-        void* p;
-        hipStream_t s;
-        ~Free() {
-            if (p) (void)hipFreeAsync(p, s);
-        }
-    } free_ws{ws, stream};
+    int rc = scratch_acquire(device, stream, kScratchWavefront, bytes, (void**)&ws);
+    if (rc != RTM_OK) return rc;
     unsigned char* q = ws;
     auto take = [&](size_t b) {
         unsigned char* r = q;
@@ -1333,7 +1385,8 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     double* aux = nullptr;
     if (scalar_scene >= 2) {
         const int n_pad = (P.scene.n + 7) & ~7;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&aux, ((size_t)n_pad * 3 + 4) * sizeof(double), stream));
+        rc = scratch_acquire(device, stream, kScratchWavefrontAux, ((size_t)n_pad * 3 + 4) * sizeof(double), (void**)&aux);
+        if (rc != RTM_OK) return rc;
         RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 4 * sizeof(double), stream));
         float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
         wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n,
@@ -1344,7 +1397,6 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
         PS.scene.wprime = aux + 4;
         PS.scene.geom32 = g32;
     }
-    Free free_aux{aux, stream};
     const unsigned grid = (unsigned)((N + 255) / 256);
     const unsigned init_counts[2] = {S.npix, 0u};
     RTM_HIP_CHECK(hipMemcpyAsync(S.n_active, init_counts, sizeof init_counts, hipMemcpyHostToDevice, stream));
@@ -1378,7 +1430,7 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     return RTM_OK;
 }
 
-// Work buffers are hipMallocAsync/hipFreeAsync pairs; without a release threshold the default pool
+// Small work buffers are hipMallocAsync/hipFreeAsync pairs; without a release threshold the default pool
 // hands multi-GB buffers back to the driver at every synchronisation and re-maps them per call.
 static void keep_stream_ordered_memory(int device) {
     static std::mutex mu;
@@ -1420,13 +1472,6 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     P.out8 = out8;
     P.counters = ds.counters;
     unsigned char* pool = nullptr;
-    struct PoolFree {
-        unsigned char* p;
-        hipStream_t s;
-        ~PoolFree() {
-            if (p) (void)hipFreeAsync(p, s);
-        }
-    };
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
     // sample split (default kernel only): per-sample terms of waves 1.. in a stream-ordered buffer
@@ -1457,12 +1502,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
             P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
             const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 192;
-            RTM_HIP_CHECK(hipMallocAsync((void**)&split_ws, (part + terms) * sizeof(double), stream));
+            rc = scratch_acquire(opt->device, stream, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
+            if (rc != RTM_OK) return rc;
             P.partial = split_ws;
             P.contrib = split_ws + part;
         }
     }
-    PoolFree split_free{reinterpret_cast<unsigned char*>(split_ws), stream};
     // deep-path record pool, stream-ordered.  Kernels with an LDS record stack take a slot only for the
     // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
     // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
@@ -1472,12 +1517,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         const size_t rec_bytes = (n <= 256) ? 1 : 4;
         P.pool_slots = packl ? grid * P.split * 64u : 65536u;
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&pool, pool_bytes + 64, stream));
+        rc = scratch_acquire(opt->device, stream, kScratchPool, pool_bytes + 64, (void**)&pool);
+        if (rc != RTM_OK) return rc;
         P.pool = pool;
         P.pool_next = reinterpret_cast<unsigned*>(pool + pool_bytes);
         RTM_HIP_CHECK(hipMemsetAsync(P.pool_next, 0, sizeof(unsigned), stream));
     }
-    PoolFree pool_free{pool, stream};
 
     unsigned long long* stamps = nullptr;
     if (opt->variant == 7) {
@@ -1497,7 +1542,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     if (wavefront) {
         // scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
         rc = run_wavefront(P, rows, stream, variant == kVariantWavefront ? 0 : variant == kVariantWavefrontScalar ? 1 :
-                                            variant == kVariantWavefrontReject ? 2 : 3);
+                                            variant == kVariantWavefrontReject ? 2 : 3, opt->device);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, tiles_y, stream);

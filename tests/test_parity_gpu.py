@@ -696,6 +696,29 @@ def test_record_packing_boundary(rtm, oracle, n):
         assert stats["casts"] == cnt["casts"]
 
 
+def test_scratch_buffers_are_reused_and_released(rtm, oracle):
+    """The big work buffers (split terms, pooled record stacks, wavefront state) persist per device and
+    stream between calls; rtm_release_scratch frees them and the next call simply allocates again."""
+    import torch
+    data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    data.width, data.height, data.samples, data.superSamples = 128, 64, 8, 2
+    r = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=2)
+    first, _ = r.render_rows_device(want=("f64",))
+    free0 = torch.cuda.mem_get_info()[0]
+    again, _ = r.render_rows_device(want=("f64",))          # reuses the buffers: no new device memory
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
+    assert rtm.lib().rtm_release_scratch(0) == 0
+    assert torch.cuda.mem_get_info()[0] > free0
+    third, _ = r.render_rows_device(want=("f64",))
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):                              # another stream gets its own buffers
+        fourth, _ = r.render_rows_device(want=("f64",), stream=s2.cuda_stream)
+    torch.cuda.synchronize()
+    for other in (again, third, fourth):
+        assert torch.equal(first["f64"], other["f64"])
+    assert rtm.lib().rtm_release_scratch(-1) == 0
+
+
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
     data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
     data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
