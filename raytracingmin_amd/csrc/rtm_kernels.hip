@@ -1406,26 +1406,33 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     int cur = 0;
     // every cast of every pixel is one trip; a pixel needs at most total_samples * (depth cap + 1)
     const unsigned long long max_trips = (unsigned long long)P.total_samples * (unsigned long long)(S.levels + 1) + 8;
-    for (unsigned long long trip = 0; na > 0; ++trip) {
+    for (unsigned long long trip = 0; na > 0;) {
         if (trip > max_trips) {
             set_last_error("wavefront loop did not terminate");
             return RTM_ERR_HIP;
         }
+        // The active count never grows, so a grid sized for the last count read back covers the trips
+        // that follow; when a trip is short (few spheres or few rays) eight of them are queued between
+        // two read-backs — blocks beyond the live list exit at once — instead of paying a host round
+        // trip per cast.
+        const int batch = ((unsigned long long)na * (unsigned long long)P.scene.n < 2000000000ull) ? 8 : 1;
         const unsigned g = (na + 255) / 256;
-        RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-        if (scalar_scene == 3)
-            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(PS, S, cur);
-        else if (scalar_scene == 2)
-            wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(PS, S, cur);
-        else if (scalar_scene == 1)
-            wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(PS, S, cur);
-        else
-            launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
-        wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
+        for (int b = 0; b < batch; ++b, ++trip) {
+            RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
+            if (scalar_scene == 3)
+                wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(PS, S, cur);
+            else if (scalar_scene == 2)
+                wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(PS, S, cur);
+            else if (scalar_scene == 1)
+                wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(PS, S, cur);
+            else
+                launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
+            wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
+            cur ^= 1;
+        }
         RTM_HIP_CHECK(hipGetLastError());
-        RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + (cur ^ 1), sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + cur, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
         RTM_HIP_CHECK(hipStreamSynchronize(stream));
-        cur ^= 1;
     }
     return RTM_OK;
 }
