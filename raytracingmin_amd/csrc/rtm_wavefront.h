@@ -3,15 +3,18 @@
 //
 // With 10^5 spheres a ray cast is ~2 M instructions of brute-force intersection against ~500 of
 // shading, so the two are split into kernels with their own register budgets:
-//   wf_nearest  one lane per ACTIVE pixel (compacted index list), nothing live but the ray and the
-//               running nearest hit: few VGPRs, many waves per SIMD.  The sphere list is streamed
-//               HBM/L2 -> LDS in tiles by the whole workgroup (coalesced 16-byte loads, double
-//               buffered through registers); all lanes read the same LDS address per sphere; a chunk
-//               of spheres the whole wave misses costs 17 flops + one compare per sphere.
-//   wf_shade    the rest of PathTracing (src/Renderer.cpp:75-117), the back-to-front fold, the
-//               per-sample accumulate and path regeneration, with the per-pixel state in HBM (SoA),
-//               then wave-ballot/prefix COMPACTION of the pixels that still have samples into the
-//               next active list.
+//   nearest hit  one lane per ACTIVE pixel (compacted index list), nothing live but the ray and the
+//                running nearest hit.  Four interchangeable kernels, oldest first:
+//                  wf_nearest_kernel                   sphere list streamed HBM/L2 -> LDS in tiles
+//                  wf_nearest_scalar_kernel<.., false> list read through the scalar cache into SGPRs
+//                  wf_nearest_scalar_kernel<.., true>  + conservative 8-FMA fp64 rejection test
+//                  wf_nearest_f32_kernel (default)     + the rejection test in packed fp32
+//                Every ray still meets every sphere, in index order, and every possible hit is
+//                decided by the reference's own arithmetic (sphere_chunk_g).
+//   wf_shade     the rest of PathTracing (src/Renderer.cpp:75-117), the back-to-front fold, the
+//                per-sample accumulate and path regeneration, with the per-pixel state in HBM (SoA),
+//                then wave-ballot/prefix COMPACTION of the pixels that still have samples into the
+//                next active list.
 // One path per pixel at a time and samples in the reference's order, so every pixel sees exactly the
 // arithmetic of render_tiles_kernel: the image is bit-identical to the other variants.
 // Per-pixel state traffic (~300 B read + written per cast) is noise next to the intersection work.
