@@ -67,7 +67,13 @@ typedef struct rtm_settings {
 } rtm_settings;
 
 enum { RTM_MODE_LITERAL = 0,  /* L0: HEAD as shipped (normal lost, recursion gets ::rand)       */
-       RTM_MODE_REPAIRED = 1  /* L1: the three one-line defects fixed    */ };
+       RTM_MODE_REPAIRED = 1, /* L1: the three one-line defects fixed    */
+       /* flag, OR-ed into mode: sin/cos of src/Renderer.cpp:93-94 return exactly what the HOST's
+        * libm returns.  The argument takes 2^23 values, so on first use the library evaluates them
+        * all on both sides (a fraction of a second, once per device) and keeps the one-ulp
+        * differences in a 4 MB table.  Costs ~2 % of a frame; makes GPU and CPU-libm renders agree
+        * bit for bit even where one-ulp differences are amplified over many bounces.            */
+       RTM_MODE_HOST_TRIG = 0x100 };
 
 typedef struct rtm_options {
     int32_t mode;         /* RTM_MODE_*                                                        */

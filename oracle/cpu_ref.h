@@ -38,6 +38,7 @@ void rtmo_cross(const double a[3], const double b[3], double out[3]);
 double rtmo_magnitude(const double a[3]);
 void rtmo_normalize(const double a[3], double out[3]);
 void rtmo_sin_cos_array(const double* x, size_t n, double* out_sin, double* out_cos);
+void rtmo_set_trace(double* buf, int capacity); /* debugging aid, see cpu_ref.c */
 
 /* src/SettingData.h:11-16 */
 float rtmo_kd(const rtm_sphere* s);

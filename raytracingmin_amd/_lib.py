@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("RTM_LIB_OVERRIDE") or os.path.join(_HERE, "librtm_hip
 
 RTM_OK = 0
 MODE_LITERAL, MODE_REPAIRED = 0, 1
+MODE_HOST_TRIG = 0x100  # flag: sin/cos exactly as the host libm returns them (include/rtm.h)
 MODES = {"literal": MODE_LITERAL, "repaired": MODE_REPAIRED, 0: 0, 1: 1}
 
 

@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -722,6 +724,12 @@ struct RayBatchParams {
     uint32_t* __restrict__ out_casts;
     uint32_t* __restrict__ scratch;  // [depth][ray] hit records, RAY_MAX_DEPTH deep
     unsigned long long* __restrict__ counters;
+    // debugging aid (RTM_DEBUG_SEAM_KEY="pixel,sample"): every ray draws from that stream instead of (i, 0),
+    // so one sample of a rendered frame can be replayed through the per-ray seam
+    int key_override;
+    uint32_t key_pixel, key_sample;
+    double* __restrict__ trace;  // debugging aid: (org, dir) of ray 0 at every cast, 6 doubles each
+    int trace_cap;
 };
 constexpr int RAY_MAX_DEPTH = 4096;
 
@@ -730,7 +738,8 @@ __global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParam
     if (i >= P.n_rays) return;
     D3 org = d3(P.org[i * 3], P.org[i * 3 + 1], P.org[i * 3 + 2]);
     D3 dir = d3(P.dir[i * 3], P.dir[i * 3 + 1], P.dir[i * 3 + 2]);
-    RngStream rng = rng_open(rng_pixel_key(P.seed_mult, (uint32_t)i), 0u);
+    RngStream rng = P.key_override ? rng_open(rng_pixel_key(P.seed_mult, P.key_pixel), P.key_sample)
+                                   : rng_open(rng_pixel_key(P.seed_mult, (uint32_t)i), 0u);
     PathCounters pc = {0, 0, 0};
     int depth = 0;
     bool overflow = false;
@@ -744,7 +753,15 @@ __global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParam
     D3 term;
     SceneGlobal sc;
     sc.v = P.scene;
+    auto log_ray = [&]() {
+        if (P.trace && i == 0 && depth < P.trace_cap) {
+            double* t = P.trace + (size_t)depth * 6;
+            t[0] = org.x; t[1] = org.y; t[2] = org.z; t[3] = dir.x; t[4] = dir.y; t[5] = dir.z;
+        }
+    };
+    log_ray();
     while (path_step<MathRef, 1>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push)) {
+        log_ray();
         if (depth >= RAY_MAX_DEPTH) {
             overflow = true;
             term = d3(0, 0, 0);
@@ -884,11 +901,23 @@ __global__ void selfcheck_kernel(int kind, unsigned long long* mismatches) {
 
 // Device primitives exposed for parity tests of the building blocks (tests/test_device_math.py).
 __global__ void math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
-                                  size_t n, double* __restrict__ out) {
+                                  size_t n, double* __restrict__ out, const uint32_t* __restrict__ fix = nullptr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double x = a[i], y = b ? b[i] : 0.0;
     double r = 0.0, s, c;
+    if (op >= 16 && op <= 18) {
+        // the draws of one bounce (RR, r1, r2) from the stream (ctr, k1) = (a, b), then the shading
+        // block's sincos of r1 corrected to the host libm: 16 -> r1, 17 -> sin, 18 -> cos
+        RngStream st{(uint32_t)x, (uint32_t)y};
+        (void)rng_next(st);
+        const double r1 = 6.283185307179586 * rng_next(st);
+        (void)rng_next(st);
+        sincos_small(r1, s, c);
+        apply_trig_fix(fix, st, s, c);
+        out[i] = op == 16 ? r1 : (op == 17 ? s : c);
+        return;
+    }
     switch (op) {
         case 0: r = sqrt(x); break;
         case 1: r = (double)__builtin_sqrtf((float)x); break;
@@ -1035,6 +1064,83 @@ struct DeviceScene {
     ~DeviceScene() { release(); }
 };
 
+// RTM_MODE_HOST_TRIG: the table that turns the device's sin/cos of r1 into the host libm's.
+// r1 = 6.283185307179586 * u with u = (2k+1) 2^-24, k < 2^23 (src/Renderer.cpp:88, rng_bits_to_u01), so
+// the whole domain is evaluated once per device: the device with the shading block's own sincos, the
+// host with glibc's sincos() (several threads; g++ -O2 turns the reference's adjacent cos(r1), sin(r1)
+// into that one call, and it is not bit-identical to sin()/cos()), and the bit-pattern differences, which must be
+// -1, 0 or +1, are packed as two signed 2-bit fields per k (sin low, cos high), 8 k per word, 4 MB.
+__global__ __launch_bounds__(256) void trig_domain_kernel(double* __restrict__ sn, double* __restrict__ cs) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const double r1 = 6.283185307179586 * rng_bits_to_u01(k << 9);
+    double s, c;
+    sincos_small(r1, s, c);
+    sn[k] = s;
+    cs[k] = c;
+}
+
+static int ensure_trig_fix(int device, const uint32_t** out) {
+    static std::mutex mu;
+    static std::map<int, uint32_t*> ready;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = ready.find(device);
+    if (it != ready.end()) {
+        *out = it->second;
+        return RTM_OK;
+    }
+    constexpr uint32_t N = 1u << 23;
+    double *d_s = nullptr, *d_c = nullptr;
+    RTM_HIP_CHECK(hipMalloc((void**)&d_s, (size_t)N * 8));
+    RTM_HIP_CHECK(hipMalloc((void**)&d_c, (size_t)N * 8));
+    trig_domain_kernel<<<N / 256, 256>>>(d_s, d_c);
+    RTM_HIP_CHECK(hipGetLastError());
+    std::vector<double> hs(N), hc(N);
+    RTM_HIP_CHECK(hipMemcpy(hs.data(), d_s, (size_t)N * 8, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(hc.data(), d_c, (size_t)N * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_s);
+    (void)hipFree(d_c);
+    std::vector<uint32_t> table(N / 8, 0u);
+    std::atomic<unsigned long long> out_of_range{0};
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+    const uint32_t words = N / 8;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            for (uint32_t w = (uint32_t)((unsigned long long)words * t / threads);
+                 w < (uint32_t)((unsigned long long)words * (t + 1) / threads); ++w) {
+                uint32_t packed = 0;
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const uint32_t k = w * 8 + j;
+                    const double r1 = 6.283185307179586 * rng_bits_to_u01(k << 9);
+                    double want[2];  // glibc sincos(): what g++ -O2 emits for the reference's cos(r1), sin(r1)
+                    ::sincos(r1, &want[0], &want[1]);
+                    const double have[2] = {hs[k], hc[k]};
+                    for (int f = 0; f < 2; ++f) {
+                        long long a, b;
+                        std::memcpy(&a, &want[f], 8);
+                        std::memcpy(&b, &have[f], 8);
+                        const long long d = a - b;
+                        if (d < -1 || d > 1) out_of_range++;
+                        packed |= ((uint32_t)(d & 3)) << (j * 4 + f * 2);
+                    }
+                }
+                table[w] = packed;
+            }
+        });
+    for (auto& th : pool) th.join();
+    if (out_of_range.load() != 0) {
+        set_last_error("host and device sin/cos differ by more than one ulp somewhere: RTM_MODE_HOST_TRIG unavailable");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    uint32_t* d_table = nullptr;
+    RTM_HIP_CHECK(hipMalloc((void**)&d_table, (size_t)words * 4));
+    RTM_HIP_CHECK(hipMemcpy(d_table, table.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+    ready[device] = d_table;
+    *out = d_table;
+    return RTM_OK;
+}
+
 // Rows a call renders and stores: the whole strip, or its bands band_index, band_index + band_count, ...
 // (8 rows each; the last band of the strip may be shorter).
 int output_rows(const rtm_options* opt) {
@@ -1067,7 +1173,7 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
         set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
-    if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {
+    if ((opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_LITERAL && (opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_REPAIRED) {
         set_last_error("unknown mode");
         return RTM_ERR_INVALID_ARGUMENT;
     }
@@ -1126,7 +1232,7 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.band_count = opt->band_count > 1 ? opt->band_count : 1;
     P.band_index = opt->band_count > 1 ? opt->band_index : 0;
     P.tiles_x = (st->width + 7) / 8;
-    P.mode = opt->mode;
+    P.mode = opt->mode & ~RTM_MODE_HOST_TRIG;
     P.max_bounces = opt->max_bounces;
     P.total_samples = (unsigned)st->super_samples * st->super_samples * st->samples;
     P.rate = (float)(1.0 / (1 + st->super_samples));
@@ -1474,6 +1580,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     std::memset(&P, 0, sizeof P);
     fill_render_params(P, st, opt);
     P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    if (opt->mode & RTM_MODE_HOST_TRIG) {
+        const uint32_t* fix = nullptr;
+        rc = ensure_trig_fix(opt->device, &fix);
+        if (rc != RTM_OK) return rc;
+        P.scene.trig_fix = fix;
+    }
     P.out64 = out64;
     P.out32 = out32;
     P.out8 = out8;
@@ -1628,7 +1740,7 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
         set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
-    if (opt->mode != RTM_MODE_LITERAL && opt->mode != RTM_MODE_REPAIRED) {
+    if ((opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_LITERAL && (opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_REPAIRED) {
         set_last_error("unknown mode");
         return RTM_ERR_INVALID_ARGUMENT;
     }
@@ -1651,9 +1763,23 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
     RayBatchParams P;
     std::memset(&P, 0, sizeof P);
     P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
-    P.mode = opt->mode;
+    if (opt->mode & RTM_MODE_HOST_TRIG) {
+        const uint32_t* fix = nullptr;
+        rc = ensure_trig_fix(opt->device, &fix);
+        if (rc != RTM_OK) return rc;
+        P.scene.trig_fix = fix;
+    }
+    P.mode = opt->mode & ~RTM_MODE_HOST_TRIG;
     P.max_bounces = opt->max_bounces;
     P.seed_mult = seed_multiplier(opt->seed);
+    if (const char* key = std::getenv("RTM_DEBUG_SEAM_KEY")) {
+        unsigned px = 0, sm = 0;
+        if (std::sscanf(key, "%u,%u", &px, &sm) == 2) {
+            P.key_override = 1;
+            P.key_pixel = px;
+            P.key_sample = sm;
+        }
+    }
     P.org = d_org;
     P.dir = d_dir;
     P.n_rays = n_rays;
@@ -1662,7 +1788,24 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
     P.out_casts = d_casts;
     P.scratch = d_scratch;
     P.counters = ds.counters;
+    const char* trace_file = std::getenv("RTM_DEBUG_SEAM_TRACE");  // file that receives ray 0's states
+    double* d_trace = nullptr;
+    if (trace_file) {
+        P.trace_cap = 256;
+        RTM_HIP_CHECK(hipMalloc((void**)&d_trace, (size_t)P.trace_cap * 6 * sizeof(double)));
+        RTM_HIP_CHECK(hipMemset(d_trace, 0, (size_t)P.trace_cap * 6 * sizeof(double)));
+        P.trace = d_trace;
+    }
     path_trace_rays_kernel<<<(unsigned)((n_rays + 63) / 64), 64>>>(P);
+    if (d_trace) {
+        std::vector<double> h((size_t)P.trace_cap * 6);
+        RTM_HIP_CHECK(hipMemcpy(h.data(), d_trace, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(trace_file, "wb")) {
+            std::fwrite(h.data(), sizeof(double), h.size(), f);
+            std::fclose(f);
+        }
+        (void)hipFree(d_trace);
+    }
     RTM_HIP_CHECK(hipGetLastError());
     RTM_HIP_CHECK(hipDeviceSynchronize());
     unsigned long long c[4];
@@ -1749,7 +1892,12 @@ int math_probe(int op, const double* a, const double* b, size_t n, double* out) 
         RTM_HIP_CHECK(hipMalloc((void**)&db, n * 8));
         RTM_HIP_CHECK(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
     }
-    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da, db, n, dout);
+    const uint32_t* fix = nullptr;
+    if (op >= 16 && op <= 18) {
+        int rc = ensure_trig_fix(0, &fix);
+        if (rc != RTM_OK) return rc;
+    }
+    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da, db, n, dout, fix);
     RTM_HIP_CHECK(hipGetLastError());
     RTM_HIP_CHECK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(da);

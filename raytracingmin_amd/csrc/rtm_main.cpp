@@ -2,7 +2,7 @@
 //
 //   rtm_cli [-?] [-json <file>] [-sampleJson]            (the reference's flags, same defaults)
 //           [--width N] [--height N] [--samples N] [--superSamples N] [--spp N]
-//           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM]
+//           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM] [--host-trig]
 //           [--gpus N] [--virtual-strips N]      (interleaved 8-row bands over N GPUs + one RCCL gather)
 //
 // Flow of the reference: pick the JSON (default settingData.json), create the sample JSON when it
@@ -32,13 +32,15 @@ static void usage() {
         "--spp N : samples = N / superSamples^2\n"
         "--mode literal|repaired (default repaired), --max-bounces N (default -1 = unlimited)\n"
         "--seed N, --device N, --out STEM (default result)\n"
+        "--host-trig : sin/cos exactly as this host's libm returns them (bit-identical to a CPU run of the reference even\n"
+        "              where deep paths amplify one-ulp differences; ~2 %% slower)\n"
         "--gpus N : interleaved 8-row bands over N GPUs of this node, one RCCL gather; --virtual-strips N : N parts on one GPU\n");
 }
 
 int main(int argc, char* argv[]) {
     std::string json_file = "settingData.json", stem = "result";
     int width = 0, height = 0, samples = 0, super_samples = 0, spp = 0;
-    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0;
+    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0, host_trig = 0;
     unsigned long long seed = 0x5EED;
     for (int i = 1; i < argc; ++i) {
         const std::string c = argv[i];
@@ -65,6 +67,7 @@ int main(int argc, char* argv[]) {
         else if (c == "--device") next_int(device);
         else if (c == "--gpus") next_int(gpus);
         else if (c == "--virtual-strips") next_int(virtual_strips);
+        else if (c == "--host-trig") host_trig = 1;
         else if (c == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
         else if (c == "--out" && i + 1 < argc) stem = argv[++i];
         else if (c == "--mode" && i + 1 < argc) {
@@ -105,7 +108,7 @@ int main(int argc, char* argv[]) {
 
     rtm_options opt;
     std::memset(&opt, 0, sizeof opt);
-    opt.mode = mode;
+    opt.mode = mode | (host_trig ? RTM_MODE_HOST_TRIG : 0);
     opt.max_bounces = max_bounces;
     opt.seed = seed;
     opt.row_begin = 0;

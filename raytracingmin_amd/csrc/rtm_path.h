@@ -298,7 +298,26 @@ struct SceneView {
     const double* __restrict__ wprime = nullptr;
     const double* __restrict__ bounds = nullptr;
     const float4* __restrict__ geom32 = nullptr;  // (float)cx, cy, cz, (float)w' (padded like wprime)
+    // RTM_MODE_HOST_TRIG: 4 bits per possible r1 (2^23 of them): the differences, in units of the last
+    // place, between the host libm's sin/cos and the device's (rtm_kernels.hip, ensure_trig_fix)
+    const uint32_t* __restrict__ trig_fix = nullptr;
 };
+
+// sin(r1), cos(r1) as the HOST's libm returns them (src/Renderer.cpp:93-94 call std::sin / std::cos):
+// r1 = 2*pi*u takes one of 2^23 values, so the device's results are compared once with the host's over
+// the whole domain and the +-1 ulp differences kept in a table (two signed 2-bit fields per r1).
+// `rng` is the stream right after the draws of r1 and r2: r1's draw is recomputed from it rather than
+// kept live, so the default path (no table) carries nothing extra.
+__device__ __forceinline__ void apply_trig_fix(const uint32_t* __restrict__ fix, const RngStream& rng, double& sn,
+                                               double& cs) {
+    const uint32_t k = mix32((rng.ctr - 2u * 0x9E3779B9u) ^ rng.k1) >> 9;
+    const uint32_t word = fix[k >> 3];
+    const int off = (int)(k & 7u) * 4;
+    const long long ds = (long long)(int)__builtin_amdgcn_sbfe(word, (unsigned)off, 2u);      // sign-extended
+    const long long dc = (long long)(int)__builtin_amdgcn_sbfe(word, (unsigned)off + 2u, 2u);
+    sn = __longlong_as_double(__double_as_longlong(sn) + ds);
+    cs = __longlong_as_double(__double_as_longlong(cs) + dc);
+}
 
 // Wave-uniform geometry fetch.  The tables are never written while a render kernel runs, but the
 // kernel also stores through unrelated pointers (pixels, pooled records), which makes hipcc fall
@@ -599,6 +618,7 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
     const D3 v = cross(w, u);  // :102
     double sn, cs;
     m.sincos_r1(r1, sn, cs);
+    if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);  // wave-uniform
     const D3 nd = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
     push(depth, id);
     depth++;

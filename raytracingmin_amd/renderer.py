@@ -20,9 +20,9 @@ from .settings import SettingData
 
 class Renderer:
     def __init__(self, data: SettingData, mode="repaired", max_bounces=-1, seed=0x5EED, device=0,
-                 variant=0):
+                 variant=0, host_trig=False):
         self.data = data  # the reference keeps a reference to the caller's SettingData
-        self.mode = _lib.MODES[mode]
+        self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0)
         self.max_bounces = int(max_bounces)
         self.seed = int(seed)
         self.device = int(device)
@@ -104,7 +104,7 @@ class Renderer:
 
 # ---- seams below the renderer, for parity tests --------------------------------------------------
 def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_bounces=-1,
-                       seed=0x5EED, device=0):
+                       seed=0x5EED, device=0, host_trig=False):
     """png::PathTracing (src/Renderer.cpp:57-117) for n rays; ray i draws from stream (seed, i, 0)."""
     org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
     direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
@@ -114,7 +114,8 @@ def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_b
     casts = np.zeros(n_rays, dtype=np.uint32)
     _, arr, n = data.to_c()
     o = rtm_options()
-    o.mode, o.max_bounces, o.seed, o.device = _lib.MODES[mode], int(max_bounces), int(seed), device
+    o.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0)
+    o.max_bounces, o.seed, o.device = int(max_bounces), int(seed), device
     _lib.check(_lib.lib().rtm_path_trace_batch(arr, n, C.byref(o), org.ctypes.data,
                                                direction.ctypes.data, n_rays, out.ctypes.data,
                                                draws.ctypes.data, casts.ctypes.data),

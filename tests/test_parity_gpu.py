@@ -739,6 +739,49 @@ def test_random_configurations_vs_oracle(rtm, oracle):
     assert checked == 120
 
 
+def test_host_trig_makes_chaotic_scenes_bit_identical(rtm, oracle):
+    """RTM_MODE_HOST_TRIG: sin/cos of the bounce (src/Renderer.cpp:93-94) exactly as the host libm returns
+    them.  Closed boxes packed with small spheres amplify one-ulp differences ~10x per bounce, so without
+    the flag deep samples diverge from the oracle there (a documented handful of the fuzzed cases); with
+    it every frame is the oracle's, bit for bit, whatever the depth."""
+    rng = np.random.default_rng(42)
+    box = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    diverged_without = 0
+    for case in range(24):
+        n = int(rng.choice([64, 100, 254, 255, 257, 400, 513]))
+        objs = list(box.object)
+        while len(objs) < n:
+            objs.append(_mk(rtm, rng.uniform(-7, 7, 3), float(rng.uniform(0.3, 1.0)), rng.uniform(0.2, 0.9, 3), (0, 0, 0)))
+        data = rtm.SettingData(width=int(rng.integers(20, 90)), height=int(rng.integers(10, 50)),
+                               samples=int(rng.choice([2, 4, 8, 16])), superSamples=int(rng.choice([1, 2, 3])),
+                               camera=box.camera, object=objs)
+        mb = int(rng.choice([-1, -1, 17, 40, 200]))
+        seed = int(rng.integers(1 << 40))
+        ost, oarr, _ = _oracle_view(oracle, data)
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=mb, seed=seed, height=data.height))
+        exact, st = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=seed, host_trig=True).render_rows(want=("f64",))
+        assert np.array_equal(exact["f64"], ref), (case, n, mb)
+        assert (st["casts"], st["draws"]) == (cnt["casts"], cnt["draws"]), case
+        plain, st = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=seed).render_rows(want=("f64",))
+        diverged_without += int(st["casts"] != cnt["casts"] or not np.array_equal(plain["f64"], ref))
+        assert float(np.max(np.abs(plain["f64"] - ref))) < 0.2  # a diverged sample moves a pixel by at most its share
+    print(f"frames differing from the oracle without the flag: {diverged_without} of 24")
+
+
+def test_device_sincos_with_host_trig_table_equals_host_libm(rtm, oracle):
+    """The table behind RTM_MODE_HOST_TRIG, through the kernels' own code path (draws of a bounce from a
+    random stream, the shading block's sincos, the correction): equal to the libm's sincos() on every
+    one of 4 M random streams."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    a = rng.integers(0, 1 << 32, n).astype(np.float64)
+    b = rng.integers(0, 1 << 32, n).astype(np.float64)
+    r1, s, c = _probe(rtm, 16, a, b), _probe(rtm, 17, a, b), _probe(rtm, 18, a, b)
+    hs, hc = oracle.sin_cos(r1)
+    assert np.array_equal(s.view(np.uint64), hs.view(np.uint64)) and np.array_equal(c.view(np.uint64), hc.view(np.uint64))
+    assert len(np.unique(r1)) > 3_000_000  # a third of the 2^23 possible arguments
+
+
 def test_scratch_buffers_are_reused_and_released(rtm, oracle):
     """The big work buffers (split terms, pooled record stacks, wavefront state) persist per device and
     stream between calls; rtm_release_scratch frees them and the next call simply allocates again."""
@@ -830,3 +873,7 @@ def test_headline_config_strip_vs_oracle(rtm, oracle):
         got[band_row_index(0, 1080, 8, rank)] = part["f64"].cpu().numpy()
         casts += st["casts"]
     assert np.array_equal(got.view(np.uint64), img.view(np.uint64)) and casts == stats["casts"]
+    # host-libm sin/cos (RTM_MODE_HOST_TRIG) change nothing here: the box's wall spheres damp one-ulp
+    # differences instead of amplifying them, which is why bench.py runs without the flag
+    exact, st = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED, host_trig=True).render_rows_device(want=("f64",))
+    assert np.array_equal(exact["f64"].cpu().numpy().view(np.uint64), img.view(np.uint64)) and st["casts"] == stats["casts"]
