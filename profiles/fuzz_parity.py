@@ -1,0 +1,57 @@
+"""Seeded parity fuzz against the CPU oracle (needs a GPU; uses tests/_oracle.py like the GPU tests do).
+    python profiles/fuzz_parity.py <seed> <cases> <host_trig 0|1>
+Random scene size and kind (open stress scene / closed box packed with small spheres), image shape,
+S, SS, bounce cap (0 .. 200 or unlimited), mode and kernel variant; every frame and its counters are
+compared with the oracle bit for bit.  Results of round 1 in profiles/r1/fuzz_parity.txt."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import _oracle as oracle  # noqa: E402
+import raytracingmin_amd as rtm  # noqa: E402
+
+seed0, cases, host_trig = int(sys.argv[1]), int(sys.argv[2]), bool(int(sys.argv[3]))
+rng = np.random.default_rng(seed0)
+box = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+
+
+def sphere(pos, r, col):
+    return rtm.SphereObject(rtm.vec3(*pos), r, rtm.Material(rtm.vec3(*col), rtm.vec3(0, 0, 0)))
+
+
+bad = 0
+for case in range(cases):
+    n = int(rng.choice([1, 2, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
+                        513, 1000]))
+    kind = case % 3
+    if kind == 0:
+        objs = list(box.object)[: max(1, min(n, 7))]
+        while len(objs) < n:
+            objs.append(sphere(rng.uniform(-7, 7, 3), float(rng.uniform(0.3, 1.0)), rng.uniform(0.2, 0.9, 3)))
+        data = rtm.SettingData(width=8, height=8, samples=1, superSamples=1, camera=box.camera, object=objs)
+    else:
+        data = rtm.make_stress_scene(n, seed=int(rng.integers(1 << 30)))
+    data.width, data.height = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+    data.samples, data.superSamples = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 32])), int(rng.choice([1, 2, 3, 4]))
+    mb = int(rng.choice([-1, -1, 0, 1, 2, 7, 8, 9, 15, 16, 17, 40, 200]))
+    mode = "literal" if case % 5 == 4 else "repaired"
+    seed = int(rng.integers(1 << 40))
+    variant = int(rng.choice([0, 0, 0, 2, 9, 13, 14, 3, 12]))
+    st, arr, cnt_n = data.to_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Sphere * max(cnt_n, 1)).from_buffer_copy(bytes(arr))
+    m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
+    r = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=variant, host_trig=host_trig)
+    out, stats = r.render_rows(0, data.height, want=("f64",))
+    ok = np.array_equal(out["f64"], ref, equal_nan=True) and \
+        (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"])
+    if not ok:
+        bad += 1
+        print("MISMATCH case", case, dict(n=n, closed_box=kind == 0, w=data.width, h=data.height, S=data.samples,
+                                          SS=data.superSamples, max_bounces=mb, mode=mode, variant=variant),
+              "max pixel delta", float(np.nanmax(np.abs(out["f64"] - ref))))
+print("seed", seed0, "cases", cases, "host_trig", host_trig, "frames differing from the oracle:", bad)
