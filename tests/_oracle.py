@@ -37,7 +37,7 @@ class Settings(C.Structure):
 class Options(C.Structure):
     _fields_ = [("mode", C.c_int32), ("max_bounces", C.c_int32), ("seed", C.c_uint64),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("device", C.c_int32),
-                ("variant", C.c_int32)]
+                ("variant", C.c_int32), ("band_count", C.c_int32), ("band_index", C.c_int32)]  # include/rtm.h layout
 
 
 class Counters(C.Structure):

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     # the oracle's view of the same PODs
     import _oracle
     assert C.sizeof(_oracle.Sphere) == 80 and C.sizeof(_oracle.Settings) == 96
-    assert C.sizeof(_oracle.Options) == 32
+    assert C.sizeof(_oracle.Options) == 40
 
 
 def test_strerror_and_variants():
