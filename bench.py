@@ -97,6 +97,9 @@ def main():
                     help="BASELINE.json configs: c2 Cornell 512x512x256spp, c3 headline (default), c4 Cornell 4K x 4096spp, "
                          "c5 100k-sphere stress scene 1080p x 256spp (use --rows to bound it)")
     ap.add_argument("--rows", default="", help="render only rows a:b of the frame (value counts those samples)")
+    ap.add_argument("--host-trig", action="store_true",
+                    help="RTM_MODE_HOST_TRIG: sin/cos exactly as the host libm returns them (~2 %% slower; the headline "
+                         "frame is bit-identical either way, tests/test_parity_gpu.py)")
     ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
                     help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
@@ -151,7 +154,7 @@ def main():
     from raytracingmin_amd.distributed import StripRenderer
     sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
                        max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant,
-                       rows=(row_lo, row_hi), layout=args.layout)
+                       rows=(row_lo, row_hi), layout=args.layout, host_trig=args.host_trig)
 
     if args.ab:
         # interleaved rounds in ONE process (guide rule 24): median/min kernel ms per variant

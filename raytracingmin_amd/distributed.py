@@ -106,7 +106,7 @@ class StripRenderer:
     step).  layout "bands": interleaved 8-row bands (default); "strips": contiguous strips."""
 
     def __init__(self, data, rank=0, world=1, device=0, mode="repaired", max_bounces=-1,
-                 seed=0x5EED, variant=0, want="f32", rows=None, layout="bands"):
+                 seed=0x5EED, variant=0, want="f32", rows=None, layout="bands", host_trig=False):
         from .renderer import Renderer
         if layout not in ("bands", "strips"):
             raise ValueError(f"unknown layout {layout!r}")
@@ -117,7 +117,7 @@ class StripRenderer:
         self.rows = self.strips[rank]
         self.want = want
         self.renderer = Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, device=device,
-                                 variant=variant)
+                                 variant=variant, host_trig=host_trig)
         self.image = None  # assembled frame on rank 0 after step()
 
     def step(self, stats=False, events=None):
