@@ -111,7 +111,8 @@ const char* rtm_variant_name(int variant);
 /* Rows a call with these options renders and stores (row_end - row_begin unless banded). */
 int rtm_output_rows(const rtm_options* options);
 /* The library keeps its large work buffers (per device and stream, grown on demand) between calls;
- * this frees them for one device, or for all with device < 0.  Waits for the device to go idle. */
+ * this frees them (and the RTM_MODE_HOST_TRIG tables) for one device, or for all with device < 0.
+ * Waits for the device to go idle. */
 int rtm_release_scratch(int device);
 
 /* ---- the hot path: Renderer::Render's pixel/sample loop (src/Renderer.cpp:215-250) ----

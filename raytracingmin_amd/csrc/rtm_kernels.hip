@@ -1079,10 +1079,14 @@ __global__ __launch_bounds__(256) void trig_domain_kernel(double* __restrict__ s
     cs[k] = c;
 }
 
+namespace {
+std::mutex g_trig_mu;
+std::map<int, uint32_t*> g_trig_ready;  // per device; dropped by release_scratch
+}  // namespace
+
 static int ensure_trig_fix(int device, const uint32_t** out) {
-    static std::mutex mu;
-    static std::map<int, uint32_t*> ready;
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_trig_mu);
+    auto& ready = g_trig_ready;
     auto it = ready.find(device);
     if (it != ready.end()) {
         *out = it->second;
@@ -1397,6 +1401,19 @@ static int scratch_acquire(int device, hipStream_t stream, int role, size_t byte
 }
 
 int release_scratch(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_trig_mu);
+        for (auto it = g_trig_ready.begin(); it != g_trig_ready.end();) {
+            if (device < 0 || it->first == device) {
+                (void)hipSetDevice(it->first);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(it->second);
+                it = g_trig_ready.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     for (auto it = g_scratch.begin(); it != g_scratch.end();) {
         if (device < 0 || it->first.device == device) {

@@ -803,6 +803,11 @@ def test_scratch_buffers_are_reused_and_released(rtm, oracle):
     for other in (again, third, fourth):
         assert torch.equal(first["f64"], other["f64"])
     assert rtm.lib().rtm_release_scratch(-1) == 0
+    # the host-trig table is dropped with the rest and rebuilt on demand
+    exact, _ = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=2, host_trig=True).render_rows_device(want=("f64",))
+    assert rtm.lib().rtm_release_scratch(0) == 0
+    exact2, _ = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=2, host_trig=True).render_rows_device(want=("f64",))
+    assert torch.equal(exact["f64"], exact2["f64"]) and torch.equal(exact["f64"], first["f64"])
 
 
 def test_row_tiles_equal_full_image_and_seed_matters(rtm, oracle):
