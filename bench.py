@@ -6,9 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one full pass of the hot path over the headline workload (BASELINE.json configs[2]):
-Cornell box (tests/golden/scenes/cornellBoxSetting.json, unchanged), 1920x1080, 1024 spp
-(superSamples 4 x samples 64), repaired (L1) semantics, max 8 bounces, fp64, seed 0x5EED, rendered
-into the HBM-resident float3 accumulation buffer.  With N > 1 the image is dealt out in interleaved
+Cornell box (scenes/cornellBoxSetting.json, unchanged), 1920x1080, 1024 spp
+(superSamples 4 x samples 64), repaired (L1) semantics, max 8 bounces, fp64, seed 0x5EED, sin/cos as the
+host libm returns them (RTM_MODE_HOST_TRIG, bit-identical to the CPU oracle; --device-trig is the labelled
+~2 % faster row), rendered into the HBM-resident float3 accumulation buffer.  With N > 1 the image is dealt out in interleaved
 8-row bands (band b -> rank b mod N; total work fixed => "strong"), and one RCCL gather to rank 0
 ends every step inside the timed region.  metric = Msamples/s = W*H*spp / s, whole job.
 
@@ -19,6 +20,12 @@ Extra objects on the JSON line:
                  for (algorithmic bytes: the float3 image written once + the scene read).
   cpu_baseline — the CPU oracle (oracle/cpu_ref.c, OpenMP, all host cores) on a bounded sample of
                  the same workload (rank 0, N = 1 only).
+  with_d2h     — the same steps with the frame copied to pinned host memory inside the timed region
+                 (SURVEY.md §8d wall time: kernel + final D2H); never the headline value.
+  other_configs— BASELINE configs[1] (5 steps) and a 64-row strip of configs[4], measured in this run
+                 outside the timed region (N = 1 only).
+Every field says whether it was measured in this run; numbers replayed from committed profiles carry
+"measured_in_run": false and the file they come from.
 """
 import argparse
 import json
@@ -82,6 +89,43 @@ def cpu_baseline(cfg, budget_rows):
     }
 
 
+def other_configs(rtm, cfg, device, host_trig):
+    """BASELINE configs[1] and a strip of configs[4], measured in this run, outside the timed region."""
+    import torch
+    out = {"measured_in_run": True}
+    data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
+    data.width, data.height, data.samples, data.superSamples = 512, 512, 16, 4
+    for name, mb in (("c2_cornell_512x512_256spp_max8", 8), ("c2_cornell_512x512_256spp_unlimited", -1)):
+        r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=cfg["seed"], device=device, host_trig=host_trig)
+        r.render_rows_device(want=("f32",), stats=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.render_rows_device(want=("f32",), stats=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        _, st = r.render_rows_device(want=("f32",), stats=True)
+        out[name] = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 5,
+                     "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+                     "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"]}
+    stress = rtm.make_stress_scene(n=100_000, seed=12345)
+    stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
+    r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
+    r.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: scene upload, buffers
+    t0 = time.perf_counter()
+    _, st = r.render_rows_device(508, 572, want=("f32",), stats=True)
+    dt = time.perf_counter() - t0
+    tests_per_s = st["casts"] * 100_000 / dt
+    out["c5_stress_100k_rows_508_572_of_1080p_256spp"] = {
+        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
+        "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+        "sphere_tests_per_s": tests_per_s,
+        "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+        "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
+        "note": "a 64-row strip fills the chip for fewer of its trips than the full frame does (profiles/)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,14 +141,19 @@ def main():
                     help="BASELINE.json configs: c2 Cornell 512x512x256spp, c3 headline (default), c4 Cornell 4K x 4096spp, "
                          "c5 100k-sphere stress scene 1080p x 256spp (use --rows to bound it)")
     ap.add_argument("--rows", default="", help="render only rows a:b of the frame (value counts those samples)")
-    ap.add_argument("--host-trig", action="store_true",
-                    help="RTM_MODE_HOST_TRIG: sin/cos exactly as the host libm returns them (~2 %% slower; the headline "
-                         "frame is bit-identical either way, tests/test_parity_gpu.py)")
+    ap.add_argument("--device-trig", action="store_true",
+                    help="the device's own sin/cos instead of RTM_MODE_HOST_TRIG (the default: sin/cos exactly as the host "
+                         "libm returns them, bit-identical to the oracle on every scene).  ~2 %% faster; the headline frame is "
+                         "bit-identical either way (tests/test_parity_gpu.py), adversarial scenes are not")
+    ap.add_argument("--host-trig", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-extras", action="store_true", help="skip with_d2h and other_configs")
     ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
                     help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo + --same-device rehearses the N-rank path on one GPU")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend (default nccl = RCCL when N > 1); gloo + --same-device rehearses the "
+                         "N-rank path on one GPU; given explicitly with N = 1 the one-rank group is created too and "
+                         "every step goes through the gather")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -124,12 +173,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_group = world > 1 or args.backend is not None
+    backend = args.backend or "nccl"
+    if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    host_trig = not args.device_trig
 
     cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
                super_samples=args.super_samples, max_bounces=args.max_bounces)
@@ -142,7 +195,7 @@ def main():
     if args.workload == "c5":
         data = rtm.make_stress_scene(n=100_000, seed=12345)
     else:
-        scene = os.path.join(ROOT, "tests", "golden", "scenes", cfg["scene"])
+        scene = os.path.join(ROOT, "scenes", cfg["scene"])
         data = rtm.LoadData(scene).data
     data.width, data.height = cfg["width"], cfg["height"]
     data.samples, data.superSamples = cfg["samples"], cfg["super_samples"]
@@ -154,14 +207,15 @@ def main():
     from raytracingmin_amd.distributed import StripRenderer
     sr = StripRenderer(data, rank=rank, world=world, device=local_rank, mode=cfg["mode"],
                        max_bounces=cfg["max_bounces"], seed=cfg["seed"], variant=args.variant,
-                       rows=(row_lo, row_hi), layout=args.layout, host_trig=args.host_trig)
+                       rows=(row_lo, row_hi), layout=args.layout, host_trig=host_trig,
+                       force_collective=use_group and world == 1)
 
     if args.ab:
         # interleaved rounds in ONE process (guide rule 24): median/min kernel ms per variant
         from raytracingmin_amd.renderer import Renderer
         vs = [int(v) for v in args.ab.split(",")]
         rs = {v: Renderer(data, mode=cfg["mode"], max_bounces=cfg["max_bounces"], seed=cfg["seed"],
-                          device=local_rank, variant=v) for v in vs}
+                          device=local_rank, variant=v, host_trig=host_trig) for v in vs}
         times = {v: [] for v in vs}
         for rnd in range(args.steps + args.warmup):
             for v in vs:
@@ -176,7 +230,7 @@ def main():
         return
 
     def barrier():
-        if world > 1:
+        if use_group:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -197,10 +251,24 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:
+    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if use_group:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(t[0]), float(t[1])
+    sr.renderer.stream_status()  # the timed steps ran without rtm_stats: a truncated path would surface here
+
+    # SURVEY.md §8(d) wall time: kernel(s) + the final D2H of the frame (rank 0 holds it after the gather)
+    with_d2h = None
+    if not args.no_extras:
+        host = torch.empty(sr.image.shape, dtype=sr.image.dtype, pin_memory=True) if rank == 0 and sr.image is not None else None
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sr.step()
+            if host is not None:
+                host.copy_(sr.image, non_blocking=True)
+        barrier()
+        with_d2h = time.perf_counter() - t1
 
     total_samples = cfg["width"] * (row_hi - row_lo) * spp
     value = total_samples * args.steps / elapsed / 1e6
@@ -221,12 +289,17 @@ def main():
         rows0 = stats["samples"] // (cfg["width"] * spp)  # rows this rank's launch stores
         alg_bytes = rows0 * cfg["width"] * 12 + n_spheres * 96
         hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         headline = args.workload == "c3" and not args.rows and \
             all(cfg[k] == HEADLINE[k] for k in ("width", "height", "samples", "super_samples", "max_bounces"))
         if world == 1 and headline and args.variant == 0 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["bytes_per_launch"]  # measured PMC bytes, committed profile
+            tj = json.load(open(tpath))
+            traffic = tj["bytes_per_launch"]  # PMC bytes of a committed rocprofv3 --pmc pass of this command
+            traffic_src = {"measured_in_run": False, "file": "profiles/latest_traffic.json",
+                           "profile": tj.get("source", "profiles/r1/default_pmc_summary.json"),
+                           "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes"}
+        resolved = rtm.lib().rtm_variant_name(stats["variant"]).decode()  # what the library ran (rtm_stats.variant)
         line = {
             "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp" if args.workload == "c3" else
                       f"Msamples/s (W*H*spp/s), BASELINE configs workload {args.workload}", "value": value,
@@ -236,14 +309,18 @@ def main():
             "config": {"workload": f"{cfg['scene']} rows {row_lo}:{row_hi} of {cfg['width']}x{cfg['height']} "
                                    f"{spp}spp (SS {cfg['super_samples']} x S {cfg['samples']}), L1 repaired, "
                                    f"max_bounces {cfg['max_bounces']}, seed 0x5EED, "
+                                   f"{'host-libm sin/cos (RTM_MODE_HOST_TRIG)' if host_trig else 'device sin/cos (--device-trig)'}, "
                                    f"{'interleaved 8-row bands' if args.layout == 'bands' else 'row strips'} over "
                                    f"{world} GPU(s) + one gather",
-                       "variant": rtm.lib().rtm_variant_name(
-                           args.variant if args.variant else (2 if n_spheres <= 24 else 14 if n_spheres < 256 else 3 if n_spheres < 512 else 12)).decode(),
+                       "variant": resolved, "sample_split_waves_per_tile": stats["split"],
+                       "collective": (f"{backend} gather, {world} rank(s)" if use_group else "none (one rank, frame stays in HBM)"),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
             "roofline": {
                 "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": traffic,
+                "traffic_source": traffic_src,
+                "achieved_source": {"measured_in_run": True, "what": "flops_per_sample (casts and bounces from this run's kernel "
+                                    "counters, D4>=0 fraction from this run's oracle sample) x samples / HIP-event kernel time"},
                 "kernel": "render_tiles_kernel" if n_spheres <= 256 else "wf_nearest_f32_kernel + wf_shade_kernel",
                 "kernel_ms": kernel_ms,
                 "flops_per_sample": f_sample,
@@ -254,8 +331,9 @@ def main():
                         "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
-        ppath = os.path.join(ROOT, "profiles", "r1", "default_pmc_summary.json")
-        if world == 1 and headline and args.variant == 0 and os.path.exists(ppath):
+        ppath = next((q for q in (os.path.join(ROOT, "profiles", "r2", "default_pmc_summary.json"),
+                                  os.path.join(ROOT, "profiles", "r1", "default_pmc_summary.json")) if os.path.exists(q)), "")
+        if world == 1 and headline and args.variant == 0 and ppath:
             # instruction-issue view of the same kernel (committed PMC pass of this command): a wave64
             # fp64 VALU instruction occupies its SIMD for 4 cycles (16 fp64 lanes per SIMD per clock)
             pmc = json.load(open(ppath))
@@ -264,7 +342,7 @@ def main():
                 "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "simds": 1024, "kernel_cycles": cyc,
                 "busy_frac_if_4_cycles_each": pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
                 "active_lanes_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / pmc["SQ_INSTS_VALU"] / 64.0,
-                "source": "profiles/r1/default_pmc_summary.json"}
+                "measured_in_run": False, "source": os.path.relpath(ppath, ROOT)}
         if n_spheres >= 512 and args.variant in (0, 12):
             # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
             # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
@@ -277,9 +355,22 @@ def main():
                         "by 8 packed-fp32 FMAs (16 flops, counted here), the rest get the reference's fp64 "
                         "arithmetic; algorithmic_fp64_tflops prices every pair at the reference's 17 flops"})
         if cpu is not None:
+            # the oracle is a restatement ("port"); what it is worth against the genuine compiled reference was
+            # measured once in the build container (the GPU box never sees /root/reference): DESIGN.md §8
+            cpu["oracle_vs_reference_ratio"] = {
+                "value": 0.89, "measured_in_run": False,
+                "provenance": "round-1 build container, Xeon 2.1 GHz, 1 thread, Cornell 256x256x64spp uncapped: oracle 1.01 vs "
+                              "the compiled reference 1.125 Msamples/s (SURVEY.md §6); L0: 4.03 vs 3.44 (ratio 1.17)"}
             line["cpu_baseline"] = cpu
+        if with_d2h is not None:
+            line["with_d2h"] = {"value": total_samples * args.steps / with_d2h / 1e6, "unit": "Msamples/s",
+                                "ms_per_step": with_d2h / args.steps * 1e3, "measured_in_run": True,
+                                "what": "the same K steps with the gathered frame copied to pinned host memory each step "
+                                        "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
+        if world == 1 and not args.no_extras and headline:
+            line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_group:
         dist.destroy_process_group()
 
 

@@ -15,6 +15,13 @@
  * handed out; every entry point returns RTM_OK (0) or a negative rtm_status, never throws.
  * "Device" pointers are HIP device pointers on the GPU selected in rtm_options.device; streams are
  * hipStream_t passed as void*.
+ *
+ * Threading: every entry point may be called from any host thread.  Renders on DIFFERENT
+ * (device, stream) pairs run concurrently and share nothing; calls that name the SAME (device, stream)
+ * are serialised by the library for the time it takes to enqueue them (the work itself is ordered by
+ * the stream), so the work buffers the library keeps per (device, stream) are never handed to two
+ * calls at once.  rtm_release_scratch waits for the renders it affects.  rtm_last_error_detail is
+ * per thread.  Diagnostic hooks (rtm_debug_*) are declared in rtm_debug.h, not here.
  */
 #ifndef RTM_H
 #define RTM_H
@@ -26,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTM_ABI_VERSION 2
+#define RTM_ABI_VERSION 3
 
 typedef enum rtm_status {
     RTM_OK = 0,
@@ -98,7 +105,16 @@ typedef struct rtm_stats {
     uint64_t bounces;     /* casts that continued (RR passed)                                  */
     uint64_t draws;       /* RNG draws consumed                                                */
     double kernel_ms;     /* device time of the render kernel(s), HIP events on the stream     */
+    int32_t variant;      /* the kernel variant that ran (rtm_options.variant resolved; see
+                             rtm_variant_name), and                                              */
+    int32_t split;        /* waves per 8x8 tile of the sample split (1 = not split)            */
 } rtm_stats;
+
+/* A scene flattened to the kernels' layout and resident on one device (opaque).  Created once,
+ * used by any number of renders on any stream of that device, destroyed by the caller after the
+ * last render that uses it has been enqueued (the library defers the release of the device
+ * memory until that work has finished). */
+typedef struct rtm_scene rtm_scene;
 
 /* ---- library ---- */
 int rtm_abi_version(void);
@@ -110,10 +126,20 @@ const char* rtm_variant_name(int variant);
 
 /* Rows a call with these options renders and stores (row_end - row_begin unless banded). */
 int rtm_output_rows(const rtm_options* options);
-/* The library keeps its large work buffers (per device and stream, grown on demand) between calls;
- * this frees them (and the RTM_MODE_HOST_TRIG tables) for one device, or for all with device < 0.
- * Waits for the device to go idle. */
+/* The library keeps its large work buffers (per device and stream, grown on demand), the scene cache
+ * of rtm_render_device and the RTM_MODE_HOST_TRIG tables between calls; this frees them for one
+ * device, or for all with device < 0.  Waits for the device to go idle.  Scenes made by
+ * rtm_scene_create are the caller's and stay. */
 int rtm_release_scratch(int device);
+
+/* ---- scene lifetime: png::SettingData::object (src/SettingData.h:47-51) on the device ----
+ * rtm_scene_create flattens `spheres` (HOST pointer, or a DEVICE pointer on `device` when
+ * spheres_on_device != 0) and uploads the tables; it returns when they are resident, so the caller's
+ * array may be freed at once.  A scene belongs to one device. */
+int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
+                     rtm_scene** out_scene);
+int rtm_scene_destroy(rtm_scene* scene);
+size_t rtm_scene_size(const rtm_scene* scene);
 
 /* ---- the hot path: Renderer::Render's pixel/sample loop (src/Renderer.cpp:215-250) ----
  * Renders rows [row_begin,row_end) of the image into caller-owned DEVICE buffers; any of the
@@ -121,12 +147,33 @@ int rtm_release_scratch(int device);
  * (src/Renderer.cpp:246-248).  out_f64 holds Renderer::image bit-for-bit semantics (double);
  * out_f32 is the same value rounded to float (the float3 accumulation buffer); out_u8 is the
  * reference's 8-bit quantisation (src/Renderer.cpp:251-254).
- * Asynchronous on `stream` unless stats != NULL (then it synchronises the stream to read the
- * counters and timing) or the scene has 512 spheres or more (the large-scene pipeline is a host
- * loop of launches that reads the active-pixel count back every iteration).  Hit records of paths deeper than the on-chip levels spill to a pooled
- * buffer (capacity: 976 bounces per path); exceeding it is reported as
- * RTM_ERR_UNSUPPORTED, which — like the counters — can only be observed when stats != NULL.
- * Scene arrays are HOST pointers (tiny for shipped scenes) unless spheres_on_device != 0. */
+ *
+ * rtm_render_scene with stats == NULL only ENQUEUES work on `stream` and returns: no allocation that
+ * synchronises, no copy from pageable memory, no wait (scenes of 512 spheres or more: the
+ * large-scene pipeline is a host loop of launches that follows the device-resident active-pixel
+ * count one batch of trips behind; the call returns when the last batch has been enqueued and the
+ * count has been seen at zero, i.e. it blocks for about the duration of the render).
+ * With stats != NULL the call synchronises the stream to read the counters and the timing.
+ *
+ * Hit records of paths deeper than the on-chip levels spill to a pooled buffer (capacity: 976
+ * bounces per path); exceeding it truncates that path and raises the stream's sticky overflow flag:
+ *   - with stats != NULL the call itself returns RTM_ERR_UNSUPPORTED;
+ *   - with stats == NULL it is reported by rtm_stream_status(device, stream) — call it after
+ *     synchronising the stream — and by the NEXT render enqueued on that stream once the flag has
+ *     reached the host (RTM_ERR_UNSUPPORTED, nothing enqueued).  The flag is cleared by the call
+ *     that reports it. */
+int rtm_render_scene(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options,
+                     double* out_f64_dev, float* out_f32_dev, uint8_t* out_u8_dev, void* stream,
+                     rtm_stats* stats);
+/* RTM_OK, or RTM_ERR_UNSUPPORTED when a render enqueued on (device, stream) since the last report
+ * overflowed its hit records.  Waits for the stream's queued work (hipStreamSynchronize). */
+int rtm_stream_status(int device, void* stream);
+
+/* The same render from a sphere ARRAY.  spheres is a HOST pointer (tiny for shipped scenes) unless
+ * spheres_on_device != 0.  Host arrays are looked up in a small per-device cache keyed by their
+ * content, so repeated calls with an unchanged scene behave like rtm_render_scene (the first call
+ * with new content uploads it and waits for the upload); device arrays are flattened on the stream
+ * per call. */
 int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
                       int spheres_on_device, const rtm_options* options, double* out_f64_dev,
                       float* out_f32_dev, uint8_t* out_u8_dev, void* stream, rtm_stats* stats);

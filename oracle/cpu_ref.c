@@ -441,6 +441,40 @@ int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
     return RTM_OK;
 }
 
+/* The same per-pixel loop (src/Renderer.cpp:222-248) for a LIST of pixels (x, y pairs): spot checks of
+ * frames too costly to render whole on the CPU.  out: n_pixels * 3 doubles. */
+int rtmo_render_pixels(const rtm_settings* st, const rtm_sphere* spheres, size_t n, const rtm_options* opt,
+                       const int32_t* xy, size_t n_pixels, double* out, rtmo_counters* counters, int threads) {
+    if (!st || !opt || !out || !xy || (!spheres && n)) return RTM_ERR_INVALID_ARGUMENT;
+    for (size_t p = 0; p < n_pixels; ++p)
+        if (xy[2 * p] < 0 || xy[2 * p] >= st->width || xy[2 * p + 1] < 0 || xy[2 * p + 1] >= st->height)
+            return RTM_ERR_INVALID_ARGUMENT;
+    v3 cx, cy, cz;
+    double fovx, fovy;
+    camera_basis(st, &cx, &cy, &cz, &fovx, &fovy);
+    const uint64_t seed_mult = seed_multiplier(opt->seed);
+    rtmo_counters total;
+    memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+#pragma omp parallel num_threads(threads)
+    {
+        rtmo_counters local;
+        memset(&local, 0, sizeof local);
+        pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL};
+#pragma omp for schedule(dynamic, 1)
+        for (long p = 0; p < (long)n_pixels; ++p)
+            render_pixel(st, &env, cx, cy, cz, fovx, fovy, seed_mult, xy[2 * p], xy[2 * p + 1], out + (size_t)p * 3);
+#pragma omp critical
+        counters_add(&total, &local);
+    }
+    if (counters) *counters = total;
+    return RTM_OK;
+}
+
 /* src/Renderer.cpp:251-254: (unsigned char)255 * std::min(image[i], 1.0), stored to u8 */
 void rtmo_quantise(const double* image, size_t n_values, uint8_t* out) {
     for (size_t i = 0; i < n_values; ++i) {

@@ -76,6 +76,10 @@ int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
                 const rtm_options* opt, double* out, rtmo_counters* counters, int threads,
                 int structure);
 
+/* The per-pixel loop of rtmo_render for a list of pixels (xy: n_pixels pairs x, y); out: n_pixels*3. */
+int rtmo_render_pixels(const rtm_settings* st, const rtm_sphere* spheres, size_t n, const rtm_options* opt,
+                       const int32_t* xy, size_t n_pixels, double* out, rtmo_counters* counters, int threads);
+
 /* Radiance of one primary sample (pixel x,y, sub-pixel sx,sy in 1..SS, sample s) before the
  * /SS/SS/S normalisation — the value the GPU's per-sample path must reproduce. */
 void rtmo_sample_radiance(const rtm_settings* st, const rtm_sphere* spheres, size_t n,

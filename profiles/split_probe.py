@@ -1,7 +1,7 @@
 import json, os, sys
 sys.path.insert(0, os.getcwd())
 import raytracingmin_amd as rtm
-scene = os.path.join("tests", "golden", "scenes", "cornellBoxSetting.json")
+scene = os.path.join("scenes", "cornellBoxSetting.json")
 data = rtm.LoadData(scene).data
 data.width, data.height, data.samples, data.superSamples = 1920, 1080, 64, 4
 r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED)

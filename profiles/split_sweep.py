@@ -5,7 +5,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracingmin_amd as rtm
 from raytracingmin_amd.distributed import partition_rows
-scene = os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "scenes", "cornellBoxSetting.json")
+scene = os.path.join(os.path.dirname(__file__), "..", "scenes", "cornellBoxSetting.json")
 data = rtm.LoadData(scene).data
 data.width, data.height, data.samples, data.superSamples = 1920, 1080, 64, 4
 r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED)

@@ -7,7 +7,7 @@ data = rtm.make_stress_scene(n=n, seed=12345)
 if len(sys.argv) > 6 and sys.argv[6] == "box":
     # a closed scene of n spheres: the Cornell box's seven plus n - 7 small ones inside it
     import os
-    box = rtm.LoadData(os.path.join("tests", "golden", "scenes", "cornellBoxSetting.json")).data
+    box = rtm.LoadData(os.path.join("scenes", "cornellBoxSetting.json")).data
     rng = np.random.default_rng(1)
     objs = list(box.object)
     for k in range(n - len(objs)):

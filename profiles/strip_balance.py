@@ -4,7 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracingmin_amd as rtm
 from raytracingmin_amd.distributed import partition_rows
-data = rtm.LoadData(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "scenes", "cornellBoxSetting.json")).data
+data = rtm.LoadData(os.path.join(os.path.dirname(__file__), "..", "scenes", "cornellBoxSetting.json")).data
 data.width, data.height, data.samples, data.superSamples = 1920, 1080, 64, 4
 r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED)
 r.render_rows_device(0, 8)

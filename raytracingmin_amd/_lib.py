@@ -44,12 +44,14 @@ class rtm_options(C.Structure):
 
 class rtm_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("casts", C.c_uint64), ("bounces", C.c_uint64),
-                ("draws", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("draws", C.c_uint64), ("kernel_ms", C.c_double), ("variant", C.c_int32),
+                ("split", C.c_int32)]
 
     def as_dict(self):
         return {"samples": int(self.samples), "casts": int(self.casts),
                 "bounces": int(self.bounces), "draws": int(self.draws),
-                "kernel_ms": float(self.kernel_ms)}
+                "kernel_ms": float(self.kernel_ms), "variant": int(self.variant),
+                "split": int(self.split)}
 
 
 # every symbol include/rtm.h declares: name -> (restype, argtypes)
@@ -63,6 +65,12 @@ SIGNATURES = {
     "rtm_release_scratch": (C.c_int, [C.c_int]),
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
+    "rtm_scene_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_void_p)]),
+    "rtm_scene_destroy": (C.c_int, [C.c_void_p]),
+    "rtm_scene_size": (C.c_size_t, [C.c_void_p]),
+    "rtm_stream_status": (C.c_int, [C.c_int, C.c_void_p]),
+    "rtm_render_scene": (C.c_int, [_P(rtm_settings), C.c_void_p, _P(rtm_options), C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, _P(rtm_stats)]),
     "rtm_render_device": (C.c_int, [_P(rtm_settings), C.c_void_p, C.c_size_t, C.c_int,
                                     _P(rtm_options), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, _P(rtm_stats)]),
@@ -85,11 +93,16 @@ SIGNATURES = {
     "rtm_write_bmp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rtm_write_jpg": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
 }
-# test hook (not in rtm.h)
-_EXTRA = {"rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-          "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
-          "rtm_debug_wf_nearest": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
-                                             C.c_void_p, C.c_void_p])}
+# test and diagnostic hooks: include/rtm_debug.h (not part of the drop-in boundary)
+DEBUG_SIGNATURES = {
+    "rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "rtm_debug_wf_nearest": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_void_p]),
+    "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(C.c_double)]),
+}
+ABI_VERSION = 3
 
 _lib = None
 
@@ -116,10 +129,10 @@ def lib():
                 f"g.build()'` or `make -C raytracingmin_amd/csrc`. There is no CPU fallback.")
         _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if L.rtm_abi_version() != 2:
+        if L.rtm_abi_version() != ABI_VERSION:
             raise ImportError("librtm_hip.so has an unexpected ABI version")
         _lib = L
     return _lib

@@ -2,6 +2,7 @@
 // implementations; no exception crosses the ABI.
 #include <exception>
 
+#include "../../include/rtm_debug.h"
 #include "rtm_internal.h"
 
 #define RTM_GUARD(call)                                  \
@@ -40,6 +41,18 @@ int rtm_output_rows(const rtm_options* options) { return options ? rtm::output_r
 int rtm_release_scratch(int device) { RTM_GUARD(rtm::release_scratch(device)) }
 const char* rtm_variant_name(int variant) { return rtm::variant_name(variant); }
 
+int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
+                     rtm_scene** out_scene) {
+    RTM_GUARD(rtm::scene_create(spheres, n_spheres, spheres_on_device, device, out_scene))
+}
+int rtm_scene_destroy(rtm_scene* scene) { RTM_GUARD(rtm::scene_destroy(scene)) }
+size_t rtm_scene_size(const rtm_scene* scene) { return rtm::scene_size(scene); }
+int rtm_stream_status(int device, void* stream) { RTM_GUARD(rtm::stream_status(device, stream)) }
+int rtm_render_scene(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options,
+                     double* out_f64_dev, float* out_f32_dev, uint8_t* out_u8_dev, void* stream,
+                     rtm_stats* stats) {
+    RTM_GUARD(rtm::render_scene(settings, scene, options, out_f64_dev, out_f32_dev, out_u8_dev, stream, stats))
+}
 int rtm_render_device(const rtm_settings* settings, const rtm_sphere* spheres, size_t n_spheres,
                       int spheres_on_device, const rtm_options* options, double* out_f64_dev,
                       float* out_f32_dev, uint8_t* out_u8_dev, void* stream, rtm_stats* stats) {
@@ -68,24 +81,20 @@ int rtm_rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sa
                   uint32_t n_draws, double* out) {
     RTM_GUARD(rtm::rng_batch(seed, pixel0, n_pixels, sample, n_draws, out))
 }
-/* test hook, not part of the documented ABI: device sqrt/sqrtf/div/sin/cos on caller data */
+/* ---- test and diagnostic hooks: declared in include/rtm_debug.h, not part of the drop-in boundary ---- */
 int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, double* out) {
     RTM_GUARD(rtm::math_probe(op, a, b, n, out))
 }
 
-/* diagnostic hook, not part of the documented ABI: isolated nearest-hit / shading loops */
 int rtm_debug_component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
                               double* cycles_per_rep) {
     RTM_GUARD(rtm::component_bench(which, sp, n, reps, blocks, lds_pad, cycles_per_rep))
 }
 
-/* test hook: the large-scene nearest-hit kernels on caller-given rays (kind 0 LDS tiles, 1 scalar
- * stream, 2 scalar stream + rejection test) */
 int rtm_debug_wf_nearest(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                          int32_t* out_id, double* out_t) {
     RTM_GUARD(rtm::wf_nearest_probe(kind, sp, n, org, dir, n_rays, out_id, out_t))
 }
-/* test hook: exhaustive device self-checks, returns the number of mismatches */
 int rtm_debug_selfcheck(int kind, unsigned long long* mismatches) { RTM_GUARD(rtm::selfcheck(kind, mismatches)) }
 
 int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,

@@ -20,6 +20,12 @@ int release_scratch(int device);
 int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                      int32_t* out_id, double* out_t);
 const char* variant_name(int v);
+int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_scene** out);
+int scene_destroy(rtm_scene* sc);
+size_t scene_size(const rtm_scene* sc);
+int stream_status(int device, void* stream);
+int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
+                 uint8_t* out8, void* stream, rtm_stats* stats);
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int spheres_on_device,
                   const rtm_options* opt, double* out64, float* out32, uint8_t* out8, void* stream,
                   rtm_stats* stats);

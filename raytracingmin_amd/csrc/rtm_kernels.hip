@@ -25,10 +25,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <tuple>
 #include <string>
 #include <type_traits>
@@ -1025,44 +1028,166 @@ __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n
     mat[i * 8 + 7] = 0.0;
 }
 
-// Scene buffers on the device for the lifetime of one call (stream-ordered).
-struct DeviceScene {
-    double* geom = nullptr;
-    double* mat = nullptr;
-    unsigned long long* counters = nullptr;
-    hipStream_t stream = nullptr;
-    int upload(const rtm_sphere* sp, size_t n, int on_device, hipStream_t st) {
-        stream = st;
-        const size_t nn = n ? n : 1;
-        RTM_HIP_CHECK(hipMallocAsync((void**)&geom, nn * 4 * sizeof(double), stream));
-        RTM_HIP_CHECK(hipMallocAsync((void**)&mat, (n + 1) * 8 * sizeof(double), stream));
-        RTM_HIP_CHECK(hipMallocAsync((void**)&counters, 4 * sizeof(unsigned long long), stream));
-        RTM_HIP_CHECK(hipMemsetAsync(counters, 0, 4 * sizeof(unsigned long long), stream));
-        if (on_device) {
-            flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, stream>>>(sp, n, geom, mat);
-            RTM_HIP_CHECK(hipGetLastError());
-        } else {
-            std::vector<double> hg, hm;
-            flatten_scene(sp, n, hg, hm);
-            // pageable source: the copy is staged before the call returns
-            if (n)
-                RTM_HIP_CHECK(hipMemcpyAsync(geom, hg.data(), hg.size() * sizeof(double),
-                                             hipMemcpyHostToDevice, stream));
-            RTM_HIP_CHECK(hipMemcpyAsync(mat, hm.data(), hm.size() * sizeof(double),
-                                         hipMemcpyHostToDevice, stream));
-            RTM_HIP_CHECK(hipStreamSynchronize(stream));
-        }
+// ---- RAII for everything the host side owns: an early return (RTM_HIP_CHECK) releases it -------
+struct DevMem {
+    void* p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;
+    DevMem& operator=(const DevMem&) = delete;
+    ~DevMem() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+    int alloc(size_t bytes) {
+        reset();
+        RTM_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
         return RTM_OK;
     }
-    void release() {
-        if (geom) (void)hipFreeAsync(geom, stream);
-        if (mat) (void)hipFreeAsync(mat, stream);
-        if (counters) (void)hipFreeAsync(counters, stream);
-        geom = mat = nullptr;
-        counters = nullptr;
-    }
-    ~DeviceScene() { release(); }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
 };
+// stream-ordered temporary (hipMallocAsync / hipFreeAsync on the same stream): no synchronisation
+struct AsyncMem {
+    void* p = nullptr;
+    hipStream_t stream = nullptr;
+    AsyncMem() = default;
+    AsyncMem(const AsyncMem&) = delete;
+    AsyncMem& operator=(const AsyncMem&) = delete;
+    ~AsyncMem() {
+        if (p) (void)hipFreeAsync(p, stream);
+    }
+    int alloc(size_t bytes, hipStream_t st) {
+        stream = st;
+        RTM_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 1, st));
+        return RTM_OK;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+struct PinnedMem {
+    void* p = nullptr;
+    ~PinnedMem() {
+        if (p) (void)hipHostFree(p);
+    }
+    int alloc(size_t bytes) {
+        RTM_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        return RTM_OK;
+    }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    int create() {
+        RTM_HIP_CHECK(hipEventCreate(&a));
+        RTM_HIP_CHECK(hipEventCreate(&b));
+        return RTM_OK;
+    }
+};
+
+}  // namespace rtm
+
+// The scene as the kernels read it, resident on one device (include/rtm.h: rtm_scene).  geom / mat as in
+// DESIGN.md §2; `aux` holds the large-scene rejection-test data (rtm_wavefront.h: bounds[4], w'[n_pad],
+// float list), computed once here instead of per render.
+struct rtm_scene {
+    int device = 0;
+    size_t n = 0;
+    rtm::DevMem geom, mat, aux;
+    uint64_t content_hash = 0;  // cache entries only
+};
+
+namespace rtm {
+
+static size_t scene_aux_doubles(size_t n) {
+    const size_t n_pad = (n + 7) & ~(size_t)7;
+    return n_pad * 3 + 4;
+}
+// bounds / w' / float list of the large-scene rejection tests, on `stream`
+static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream_t stream) {
+    const int n_pad = (int)((n + 7) & ~(size_t)7);
+    RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 4 * sizeof(double), stream));
+    float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
+    if (n_pad > 0) {
+        wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>((const double4*)geom, (int)n,
+                                                                      reinterpret_cast<long long*>(aux + 2));
+        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>((const double4*)geom, (int)n, n_pad, aux + 4,
+                                                                    reinterpret_cast<unsigned long long*>(aux), g32);
+    }
+    RTM_HIP_CHECK(hipGetLastError());
+    return RTM_OK;
+}
+static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n) {
+    SceneView v{(const double4*)geom, mat, (int)n};
+    if (aux) {
+        const size_t n_pad = (n + 7) & ~(size_t)7;
+        v.bounds = aux;
+        v.wprime = aux + 4;
+        v.geom32 = reinterpret_cast<const float4*>(aux + 4 + n_pad);
+    }
+    return v;
+}
+
+// Flatten + upload a HOST sphere array; returns when the tables are resident (the caller's array and
+// the staging vectors may go away).  Runs on the device's null stream.
+static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int device) {
+    RTM_HIP_CHECK(hipSetDevice(device));
+    sc.device = device;
+    sc.n = n;
+    std::vector<double> hg, hm;
+    flatten_scene(sp, n, hg, hm);
+    int rc = sc.geom.alloc((n ? n : 1) * 4 * sizeof(double));
+    if (rc == RTM_OK) rc = sc.mat.alloc((n + 1) * 8 * sizeof(double));
+    if (rc == RTM_OK) rc = sc.aux.alloc(scene_aux_doubles(n) * sizeof(double));
+    if (rc != RTM_OK) return rc;
+    if (n) RTM_HIP_CHECK(hipMemcpy(sc.geom.p, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(sc.mat.p, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice));
+    rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
+    if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return RTM_OK;
+}
+// The same from a DEVICE sphere array.
+static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n, int device) {
+    RTM_HIP_CHECK(hipSetDevice(device));
+    sc.device = device;
+    sc.n = n;
+    int rc = sc.geom.alloc((n ? n : 1) * 4 * sizeof(double));
+    if (rc == RTM_OK) rc = sc.mat.alloc((n + 1) * 8 * sizeof(double));
+    if (rc == RTM_OK) rc = sc.aux.alloc(scene_aux_doubles(n) * sizeof(double));
+    if (rc != RTM_OK) return rc;
+    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256>>>(sp_dev, n, sc.geom.as<double>(), sc.mat.as<double>());
+    RTM_HIP_CHECK(hipGetLastError());
+    rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
+    if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return RTM_OK;
+}
+
+int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_scene** out) {
+    if (!out || (!sp && n) || n > 0x7FFFFFFFull) {
+        set_last_error("null argument or scene too large");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    *out = nullptr;
+    std::unique_ptr<rtm_scene> sc(new rtm_scene);
+    const int rc = on_device ? scene_build_device(*sc, sp, n, device) : scene_build_host(*sc, sp, n, device);
+    if (rc != RTM_OK) return rc;
+    *out = sc.release();
+    return RTM_OK;
+}
+int scene_destroy(rtm_scene* sc) {
+    if (!sc) return RTM_OK;
+    // renders that use the scene may still be queued: wait for the device before its memory goes
+    if (hipSetDevice(sc->device) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    delete sc;
+    return RTM_OK;
+}
+size_t scene_size(const rtm_scene* sc) { return sc ? sc->n : 0; }
 
 // RTM_MODE_HOST_TRIG: the table that turns the device's sin/cos of r1 into the host libm's.
 // r1 = 6.283185307179586 * u with u = (2k+1) 2^-24, k < 2^23 (src/Renderer.cpp:88, rng_bits_to_u01), so
@@ -1093,16 +1218,16 @@ static int ensure_trig_fix(int device, const uint32_t** out) {
         return RTM_OK;
     }
     constexpr uint32_t N = 1u << 23;
-    double *d_s = nullptr, *d_c = nullptr;
-    RTM_HIP_CHECK(hipMalloc((void**)&d_s, (size_t)N * 8));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_c, (size_t)N * 8));
-    trig_domain_kernel<<<N / 256, 256>>>(d_s, d_c);
-    RTM_HIP_CHECK(hipGetLastError());
     std::vector<double> hs(N), hc(N);
-    RTM_HIP_CHECK(hipMemcpy(hs.data(), d_s, (size_t)N * 8, hipMemcpyDeviceToHost));
-    RTM_HIP_CHECK(hipMemcpy(hc.data(), d_c, (size_t)N * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d_s);
-    (void)hipFree(d_c);
+    {
+        DevMem d_s, d_c;
+        int rc;
+        if ((rc = d_s.alloc((size_t)N * 8)) != RTM_OK || (rc = d_c.alloc((size_t)N * 8)) != RTM_OK) return rc;
+        trig_domain_kernel<<<N / 256, 256>>>(d_s.as<double>(), d_c.as<double>());
+        RTM_HIP_CHECK(hipGetLastError());
+        RTM_HIP_CHECK(hipMemcpy(hs.data(), d_s.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+        RTM_HIP_CHECK(hipMemcpy(hc.data(), d_c.p, (size_t)N * 8, hipMemcpyDeviceToHost));
+    }
     std::vector<uint32_t> table(N / 8, 0u);
     std::atomic<unsigned long long> out_of_range{0};
     unsigned threads = std::thread::hardware_concurrency();
@@ -1137,11 +1262,13 @@ static int ensure_trig_fix(int device, const uint32_t** out) {
         set_last_error("host and device sin/cos differ by more than one ulp somewhere: RTM_MODE_HOST_TRIG unavailable");
         return RTM_ERR_UNSUPPORTED;
     }
-    uint32_t* d_table = nullptr;
-    RTM_HIP_CHECK(hipMalloc((void**)&d_table, (size_t)words * 4));
-    RTM_HIP_CHECK(hipMemcpy(d_table, table.data(), (size_t)words * 4, hipMemcpyHostToDevice));
-    ready[device] = d_table;
-    *out = d_table;
+    DevMem d_table;
+    const int rc = d_table.alloc((size_t)words * 4);
+    if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipMemcpy(d_table.p, table.data(), (size_t)words * 4, hipMemcpyHostToDevice));
+    ready[device] = d_table.as<uint32_t>();
+    *out = d_table.as<uint32_t>();
+    d_table.p = nullptr;  // owned by g_trig_ready until release_scratch
     return RTM_OK;
 }
 
@@ -1359,36 +1486,104 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     }
 }
 
-// Large work buffers (the sample split's term buffer, the pooled record stacks, the wavefront state)
-// are kept per (device, stream, role) and grown on demand: calls on one stream are ordered by the stream,
-// so the buffer of the previous call can be reused without any wait, and different streams get
-// different buffers.  Allocating them stream-ordered per call instead let the pool hand out FRESH
-// multi-GB blocks whenever the host ran ahead of the GPU (a 2.4 GB first touch per step: 10 -> 40 ms
-// for a 512x512 unlimited-depth frame, intermittently).  release_scratch() frees them.
+// ---- per-(device, stream) context -----------------------------------------------------------------
+// Large work buffers (the sample split's term buffer, the pooled record stacks, the wavefront state) are kept
+// per (device, stream, role) and grown on demand: calls on one stream are ordered by the stream, so the
+// buffer of the previous call can be reused without any wait, and different streams get different buffers.
+// Allocating them stream-ordered per call instead let the pool hand out FRESH multi-GB blocks whenever the
+// host ran ahead of the GPU (a 2.4 GB first touch per step: 10 -> 40 ms for a 512x512 unlimited-depth frame,
+// intermittently).  release_scratch() frees them.
+//
+// The context also owns the stream's STICKY status word: renders without rtm_stats count into `sticky`
+// (casts, bounces, draws — ignored — and the overflow flag, which only ever gets OR-ed), every render ends
+// with a stream-ordered copy of the flag into a pinned host word, and the next call / rtm_stream_status
+// report it.  Threading (include/rtm.h): `mu` is held while a call enqueues its work, so two host threads
+// naming the same (device, stream) take turns and never see each other's half-grown buffers; `g_gate` is
+// held shared by every render and exclusively by release_scratch, which therefore never frees anything
+// under a call that is between acquiring a buffer and launching on it.
+enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchRoles = 3 };
 namespace {
-struct ScratchKey {
-    int device;
-    hipStream_t stream;
-    int role;
-    bool operator<(const ScratchKey& o) const {
-        return std::tie(device, stream, role) < std::tie(o.device, o.stream, o.role);
-    }
-};
 struct ScratchBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
 };
-std::mutex g_scratch_mu;
-std::map<ScratchKey, ScratchBuf> g_scratch;
-}  // namespace
-enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchWavefrontAux = 3 };
+struct StreamCtx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ScratchBuf scratch[kScratchRoles];
+    unsigned long long* sticky = nullptr;    // device: casts, bounces, draws (ignored), overflow flag
+    unsigned long long* counters = nullptr;  // device: the same four words for a call WITH stats
+    unsigned long long* flag_host = nullptr; // pinned: last copy of sticky[3]
+    unsigned* wf_count_host = nullptr;       // pinned: [2] active-pixel counts of the large-scene pipeline
+    bool ready = false;
+    int init() {
+        if (ready) return RTM_OK;
+        RTM_HIP_CHECK(hipMalloc((void**)&sticky, 8 * sizeof(unsigned long long)));
+        counters = sticky + 4;
+        RTM_HIP_CHECK(hipMemset(sticky, 0, 8 * sizeof(unsigned long long)));
+        RTM_HIP_CHECK(hipHostMalloc((void**)&flag_host, 64, hipHostMallocDefault));
+        std::memset(flag_host, 0, 64);
+        wf_count_host = reinterpret_cast<unsigned*>(flag_host + 2);
+        ready = true;
+        return RTM_OK;
+    }
+    void free_all() {  // caller: device idle, nobody else in the context
+        for (auto& b : scratch) {
+            if (b.ptr) (void)hipFree(b.ptr);
+            b = ScratchBuf{};
+        }
+        if (sticky) (void)hipFree(sticky);
+        if (flag_host) (void)hipHostFree(flag_host);
+        sticky = counters = flag_host = nullptr;
+        wf_count_host = nullptr;
+        ready = false;
+    }
+};
+std::shared_mutex g_gate;  // shared: a render is being enqueued; exclusive: release_scratch
+std::mutex g_ctx_mu;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<StreamCtx>> g_ctx;
 
-static int scratch_acquire(int device, hipStream_t stream, int role, size_t bytes, void** out) {
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    ScratchBuf& b = g_scratch[ScratchKey{device, stream, role}];
+StreamCtx* get_ctx(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    auto& slot = g_ctx[{device, stream}];
+    if (!slot) {
+        slot.reset(new StreamCtx);
+        slot->device = device;
+        slot->stream = stream;
+    }
+    return slot.get();
+}
+
+// Scene cache of rtm_render_device(host array): content-addressed, a few entries per process.
+// Entries are shared: a render keeps its scene alive while it enqueues, and whoever drops the last reference
+// (an eviction, release_scratch, or that render) waits for the device before the tables are freed.
+struct SceneCache {
+    std::mutex mu;
+    std::vector<std::shared_ptr<rtm_scene>> entries;  // most recently used last
+} g_scene_cache;
+constexpr size_t kSceneCacheEntries = 8;
+
+uint64_t hash_bytes(const void* data, size_t bytes) {  // FNV-1a over 8-byte words (+ tail bytes)
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint64_t h = 1469598103934665603ull;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 1099511628211ull;
+    }
+    for (; i < bytes; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+}  // namespace
+
+// Caller holds ctx.mu.  Growing waits for the stream (queued work may still use the smaller buffer).
+static int scratch_acquire(StreamCtx& ctx, int role, size_t bytes, void** out) {
+    ScratchBuf& b = ctx.scratch[role];
     if (b.bytes < bytes) {
-        if (b.ptr) {  // the previous, smaller buffer may still be in use by queued work of this stream
-            RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        if (b.ptr) {
+            RTM_HIP_CHECK(hipStreamSynchronize(ctx.stream));
             (void)hipFree(b.ptr);
             b.ptr = nullptr;
             b.bytes = 0;
@@ -1400,7 +1595,32 @@ static int scratch_acquire(int device, hipStream_t stream, int role, size_t byte
     return RTM_OK;
 }
 
+// The cached scene for a host array (uploading it on a miss).
+static int cached_scene(const rtm_sphere* sp, size_t n, int device, std::shared_ptr<rtm_scene>* out) {
+    const uint64_t h = hash_bytes(sp, n * sizeof(rtm_sphere));
+    std::lock_guard<std::mutex> lock(g_scene_cache.mu);
+    auto& e = g_scene_cache.entries;
+    for (size_t i = 0; i < e.size(); ++i)
+        if (e[i]->device == device && e[i]->n == n && e[i]->content_hash == h) {
+            if (i + 1 != e.size()) std::rotate(e.begin() + (long)i, e.begin() + (long)i + 1, e.end());
+            *out = e.back();
+            return RTM_OK;
+        }
+    std::shared_ptr<rtm_scene> sc(new rtm_scene, [](rtm_scene* p) { (void)scene_destroy(p); });
+    const int rc = scene_build_host(*sc, sp, n, device);
+    if (rc != RTM_OK) return rc;
+    sc->content_hash = h;
+    if (e.size() >= kSceneCacheEntries) {
+        e.erase(e.begin());
+        RTM_HIP_CHECK(hipSetDevice(device));
+    }
+    e.push_back(sc);
+    *out = sc;
+    return RTM_OK;
+}
+
 int release_scratch(int device) {
+    std::unique_lock<std::shared_mutex> gate(g_gate);  // no render is mid-call from here on
     {
         std::lock_guard<std::mutex> lock(g_trig_mu);
         for (auto it = g_trig_ready.begin(); it != g_trig_ready.end();) {
@@ -1414,17 +1634,29 @@ int release_scratch(int device) {
             }
         }
     }
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    for (auto it = g_scratch.begin(); it != g_scratch.end();) {
-        if (device < 0 || it->first.device == device) {
-            (void)hipSetDevice(it->first.device);
+    {
+        std::lock_guard<std::mutex> lock(g_scene_cache.mu);
+        auto& e = g_scene_cache.entries;
+        for (auto it = e.begin(); it != e.end();) {
+            if (device < 0 || (*it)->device == device) {
+                it = e.erase(it);  // the deleter waits for the device
+            } else {
+                ++it;
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (auto it = g_ctx.begin(); it != g_ctx.end();) {
+        if (device < 0 || it->first.first == device) {
+            (void)hipSetDevice(it->first.first);
             (void)hipDeviceSynchronize();
-            if (it->second.ptr) (void)hipFree(it->second.ptr);
-            it = g_scratch.erase(it);
+            it->second->free_all();
+            it = g_ctx.erase(it);
         } else {
             ++it;
         }
     }
+    (void)hipGetLastError();
     return RTM_OK;
 }
 
@@ -1456,22 +1688,28 @@ static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int devic
     return g;
 }
 
-// Wavefront pipeline for large scenes (rtm_wavefront.h): host loop of nearest / shade launches until
-// the compacted active list is empty.  Synchronous: the list length is read back every iteration.
+// Wavefront pipeline for large scenes (rtm_wavefront.h): nearest / shade launches until the compacted active
+// list is empty.  The active count stays on the device: launches are queued a batch of trips at a time, a
+// batch ends with a stream-ordered copy of the count into a pinned host word, and the host reads the count
+// of batch b-1 only after batch b has been queued behind it — the GPU never waits for the host.  The count
+// never grows, so a grid sized for the last count seen covers the trips queued after it (blocks beyond the
+// live list exit at once), and the batch queued when the zero is finally seen is a handful of empty
+// launches.
 template <int TILE, int K, int R>
 static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, unsigned na, hipStream_t stream) {
     const unsigned g = (na + 256 * R - 1) / (256 * R);
     wf_nearest_kernel<MathFast, TILE, K, R><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
 }
 
-static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, int scalar_scene, int device) {
+static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int scalar_scene) {
     // (TILE, K, R) = (512 spheres per LDS tile, 4 per chunk, 1 ray per lane): profiles/r1/wf_tune.txt —
     // smaller chunks or 2-4 rays per lane (fewer LDS reads per ray, fewer waves) were 0-50 % slower
+    hipStream_t stream = ctx.stream;
     WfState S;
     std::memset(&S, 0, sizeof S);
     S.npix = (unsigned)rows * (unsigned)P.W;
     // record levels per pixel: the cap when there is one, else as many as 2 GiB of HBM buy
-    // (64..1024); a deeper path fails loudly like in the other variants
+    // (64..1024); a deeper path raises the overflow flag like in the other variants
     if (P.max_bounces >= 0 && P.max_bounces <= 1024) {
         S.levels = P.max_bounces > 0 ? P.max_bounces : 1;
     } else {
@@ -1481,7 +1719,7 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     const size_t N = S.npix;
     const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256;
     unsigned char* ws = nullptr;
-    int rc = scratch_acquire(device, stream, kScratchWavefront, bytes, (void**)&ws);
+    int rc = scratch_acquire(ctx, kScratchWavefront, bytes, (void**)&ws);
     if (rc != RTM_OK) return rc;
     unsigned char* q = ws;
     auto take = [&](size_t b) {
@@ -1504,58 +1742,58 @@ static int run_wavefront(const RenderParams& P, int rows, hipStream_t stream, in
     S.active[0] = (unsigned*)take(N * 4);
     S.active[1] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
-    RenderParams PS = P;  // + the rejection test's per-sphere data
-    double* aux = nullptr;
-    if (scalar_scene >= 2) {
-        const int n_pad = (P.scene.n + 7) & ~7;
-        rc = scratch_acquire(device, stream, kScratchWavefrontAux, ((size_t)n_pad * 3 + 4) * sizeof(double), (void**)&aux);
-        if (rc != RTM_OK) return rc;
-        RTM_HIP_CHECK(hipMemsetAsync(aux, 0, 4 * sizeof(double), stream));
-        float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
-        wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n,
-                                                                      reinterpret_cast<long long*>(aux + 2));
-        wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>(P.scene.geom, P.scene.n, n_pad, aux + 4,
-                                                                    reinterpret_cast<unsigned long long*>(aux), g32);
-        PS.scene.bounds = aux;
-        PS.scene.wprime = aux + 4;
-        PS.scene.geom32 = g32;
+    if (scalar_scene >= 2 && !P.scene.geom32) {
+        set_last_error("scene without rejection-test data");
+        return RTM_ERR_INVALID_ARGUMENT;
     }
     const unsigned grid = (unsigned)((N + 255) / 256);
-    const unsigned init_counts[2] = {S.npix, 0u};
-    RTM_HIP_CHECK(hipMemcpyAsync(S.n_active, init_counts, sizeof init_counts, hipMemcpyHostToDevice, stream));
-    wf_init_kernel<<<grid, 256, 0, stream>>>(P, S);
+    wf_init_kernel<<<grid, 256, 0, stream>>>(P, S);  // also sets n_active = {npix, 0}
     RTM_HIP_CHECK(hipGetLastError());
-    unsigned na = S.npix;
+
+    struct Events {
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~Events() {
+            for (auto v : e)
+                if (v) (void)hipEventDestroy(v);
+        }
+    } ev;
+    for (auto& v : ev.e) RTM_HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+
+    unsigned na = S.npix;  // last count the host has seen (an upper bound of the device's)
     int cur = 0;
     // every cast of every pixel is one trip; a pixel needs at most total_samples * (depth cap + 1)
     const unsigned long long max_trips = (unsigned long long)P.total_samples * (unsigned long long)(S.levels + 1) + 8;
-    for (unsigned long long trip = 0; na > 0;) {
-        if (trip > max_trips) {
+    unsigned long long trip = 0;
+    for (unsigned long long b = 0;; ++b) {
+        if (trip > max_trips + 64) {
             set_last_error("wavefront loop did not terminate");
             return RTM_ERR_HIP;
         }
-        // The active count never grows, so a grid sized for the last count read back covers the trips
-        // that follow; when a trip is short (few spheres or few rays) eight of them are queued between
-        // two read-backs — blocks beyond the live list exit at once — instead of paying a host round
-        // trip per cast.
+        // short trips (few spheres or few rays): eight per batch, so that the host's lag of one batch hides the
+        // read-back; long trips: one
         const int batch = ((unsigned long long)na * (unsigned long long)P.scene.n < 2000000000ull) ? 8 : 1;
         const unsigned g = (na + 255) / 256;
-        for (int b = 0; b < batch; ++b, ++trip) {
+        for (int k = 0; k < batch; ++k, ++trip) {
             RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
             if (scalar_scene == 3)
-                wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(PS, S, cur);
+                wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(P, S, cur);
             else if (scalar_scene == 2)
-                wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(PS, S, cur);
+                wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(P, S, cur);
             else if (scalar_scene == 1)
-                wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(PS, S, cur);
+                wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(P, S, cur);
             else
                 launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
             wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
             cur ^= 1;
         }
         RTM_HIP_CHECK(hipGetLastError());
-        RTM_HIP_CHECK(hipMemcpyAsync(&na, S.n_active + cur, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-        RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        RTM_HIP_CHECK(hipMemcpyAsync(&ctx.wf_count_host[b & 1], S.n_active + cur, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+        RTM_HIP_CHECK(hipEventRecord(ev.e[b & 1], stream));
+        if (b >= 1) {  // batch b is queued: now look at what batch b-1 left
+            RTM_HIP_CHECK(hipEventSynchronize(ev.e[(b - 1) & 1]));
+            na = ctx.wf_count_host[(b - 1) & 1];
+            if (na == 0) break;
+        }
     }
     return RTM_OK;
 }
@@ -1577,26 +1815,50 @@ static void keep_stream_ordered_memory(int device) {
     (void)hipGetLastError();
 }
 
-int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
-                  const rtm_options* opt, double* out64, float* out32, uint8_t* out8,
-                  void* stream_v, rtm_stats* stats) {
-    int rc = validate(st, sp, n, opt);
-    if (rc != RTM_OK) return rc;
-    hipStream_t stream = (hipStream_t)stream_v;
+static const char* kOverflowText =
+    "a path ran deeper than the hit-record capacity (16-64 on-chip levels + 960 pooled levels)";
+
+// Report-and-clear of the stream's sticky overflow flag.  Caller holds ctx.mu; `wait` synchronises first.
+static int take_stream_status(StreamCtx& ctx, bool wait) {
+    if (!ctx.ready) return RTM_OK;
+    if (wait) RTM_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    if (*(volatile unsigned long long*)ctx.flag_host == 0ull) return RTM_OK;
+    // error path: make sure no copy of the old flag is still in flight, then clear both sides
+    RTM_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    RTM_HIP_CHECK(hipMemsetAsync(ctx.sticky + 3, 0, sizeof(unsigned long long), ctx.stream));
+    RTM_HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    *ctx.flag_host = 0ull;
+    set_last_error(std::string("an earlier render on this stream was truncated: ") + kOverflowText);
+    return RTM_ERR_UNSUPPORTED;
+}
+
+int stream_status(int device, void* stream_v) {
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    RTM_HIP_CHECK(hipSetDevice(device));
+    StreamCtx* ctx = get_ctx(device, (hipStream_t)stream_v);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return take_stream_status(*ctx, true);
+}
+
+// The render proper: `view` is resident on opt->device and stays valid until the queued work has run.
+// The caller holds g_gate (shared).
+static int render_view(const rtm_settings* st, const SceneView& view, size_t n, const rtm_options* opt,
+                       double* out64, float* out32, uint8_t* out8, hipStream_t stream, rtm_stats* stats) {
     RTM_HIP_CHECK(hipSetDevice(opt->device));
-    keep_stream_ordered_memory(opt->device);
     const int rows = output_rows(opt);
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (rows == 0) return RTM_OK;
-
-    DeviceScene ds;
-    rc = ds.upload(sp, n, on_device, stream);
+    StreamCtx& ctx = *get_ctx(opt->device, stream);
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    int rc = ctx.init();
     if (rc != RTM_OK) return rc;
+    rc = take_stream_status(ctx, false);  // an overflow of an earlier render that has reached the host
+    if (rc != RTM_OK) return rc;
+    if (rows == 0) return RTM_OK;
 
     RenderParams P;
     std::memset(&P, 0, sizeof P);
     fill_render_params(P, st, opt);
-    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    P.scene = view;
     if (opt->mode & RTM_MODE_HOST_TRIG) {
         const uint32_t* fix = nullptr;
         rc = ensure_trig_fix(opt->device, &fix);
@@ -1606,11 +1868,12 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     P.out64 = out64;
     P.out32 = out32;
     P.out8 = out8;
-    P.counters = ds.counters;
+    P.counters = stats ? ctx.counters : ctx.sticky;
+    if (stats) RTM_HIP_CHECK(hipMemsetAsync(ctx.counters, 0, 4 * sizeof(unsigned long long), stream));
     unsigned char* pool = nullptr;
     const unsigned tiles_y = (unsigned)((rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
-    // sample split (default kernel only): per-sample terms of waves 1.. in a stream-ordered buffer
+    // sample split (default kernel only): per-sample terms of waves 1.. in the stream's term buffer
     int variant = opt->variant;
     double* split_ws = nullptr;
     P.n_tiles = grid;
@@ -1638,13 +1901,13 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
             P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
             const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 192;
-            rc = scratch_acquire(opt->device, stream, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
+            rc = scratch_acquire(ctx, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
             if (rc != RTM_OK) return rc;
             P.partial = split_ws;
             P.contrib = split_ws + part;
         }
     }
-    // deep-path record pool, stream-ordered.  Kernels with an LDS record stack take a slot only for the
+    // deep-path record pool.  Kernels with an LDS record stack take a slot only for the
     // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
     // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
     const bool packl = n < 256 && !(P.max_bounces >= 0 && P.max_bounces <= 8) &&
@@ -1653,69 +1916,121 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         const size_t rec_bytes = (n <= 256) ? 1 : 4;
         P.pool_slots = packl ? grid * P.split * 64u : 65536u;
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
-        rc = scratch_acquire(opt->device, stream, kScratchPool, pool_bytes + 64, (void**)&pool);
+        rc = scratch_acquire(ctx, kScratchPool, pool_bytes + 64, (void**)&pool);
         if (rc != RTM_OK) return rc;
         P.pool = pool;
         P.pool_next = reinterpret_cast<unsigned*>(pool + pool_bytes);
         RTM_HIP_CHECK(hipMemsetAsync(P.pool_next, 0, sizeof(unsigned), stream));
     }
 
-    unsigned long long* stamps = nullptr;
+    DevMem stamps;
     if (opt->variant == 7) {
-        RTM_HIP_CHECK(hipMalloc((void**)&stamps, (size_t)grid * 4 * sizeof(unsigned long long)));
-        RTM_HIP_CHECK(hipMemset(stamps, 0, (size_t)grid * 4 * sizeof(unsigned long long)));
-        P.stamps = stamps;
+        rc = stamps.alloc((size_t)grid * 4 * sizeof(unsigned long long));
+        if (rc != RTM_OK) return rc;
+        RTM_HIP_CHECK(hipMemset(stamps.p, 0, (size_t)grid * 4 * sizeof(unsigned long long)));
+        P.stamps = stamps.as<unsigned long long>();
     }
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    EventPair ev;
     if (stats) {
-        RTM_HIP_CHECK(hipEventCreate(&ev0));
-        RTM_HIP_CHECK(hipEventCreate(&ev1));
-        RTM_HIP_CHECK(hipEventRecord(ev0, stream));
+        rc = ev.create();
+        if (rc != RTM_OK) return rc;
+        RTM_HIP_CHECK(hipEventRecord(ev.a, stream));
     }
     const bool wavefront = variant == kVariantWavefront || variant == kVariantWavefrontScalar ||
                            variant == kVariantWavefrontReject || variant == kVariantWavefrontRejectF32;
     if (wavefront) {
         // scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
-        rc = run_wavefront(P, rows, stream, variant == kVariantWavefront ? 0 : variant == kVariantWavefrontScalar ? 1 :
-                                            variant == kVariantWavefrontReject ? 2 : 3, opt->device);
+        rc = run_wavefront(P, rows, ctx, variant == kVariantWavefront ? 0 : variant == kVariantWavefrontScalar ? 1 :
+                                         variant == kVariantWavefrontReject ? 2 : 3);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, tiles_y, stream);
     }
     RTM_HIP_CHECK(hipGetLastError());
-    if (stamps) {  // diagnostic variant: print the per-wave segment shares
+    if (stamps.p) {  // diagnostic variant: print the per-wave segment shares
         RTM_HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<unsigned long long> h((size_t)grid * 4);
-        RTM_HIP_CHECK(hipMemcpy(h.data(), stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        RTM_HIP_CHECK(hipMemcpy(h.data(), stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         double a[4] = {0, 0, 0, 0};
         for (size_t b = 0; b < grid; ++b)
             for (int k = 0; k < 4; ++k) a[k] += (double)h[b * 4 + k];
         std::fprintf(stderr,
                      "[rtm stamps] per wave-iteration cycles: nearest %.0f, shade %.0f, end+loop %.0f (iterations/wave %.0f)\n",
                      a[0] / a[3], a[1] / a[3], a[2] / a[3], a[3] / grid);
-        (void)hipFree(stamps);
     }
-    if (stats) {
-        RTM_HIP_CHECK(hipEventRecord(ev1, stream));
-        unsigned long long c[4];
-        RTM_HIP_CHECK(hipMemcpyAsync(c, ds.counters, sizeof c, hipMemcpyDeviceToHost, stream));
-        RTM_HIP_CHECK(hipStreamSynchronize(stream));
-        float ms = 0.f;
-        RTM_HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
-        stats->samples = (uint64_t)rows * st->width * P.total_samples;
-        stats->casts = c[0];
-        stats->bounces = c[1];
-        stats->draws = c[2];
-        stats->kernel_ms = ms;
-        if (c[3]) {
-            set_last_error("a path ran deeper than the hit-record capacity (16-64 on-chip levels + 960 pooled levels)");
-            return RTM_ERR_UNSUPPORTED;
-        }
+    if (!stats) {
+        // the stream's sticky flag travels to the host behind the render, without anybody waiting for it
+        RTM_HIP_CHECK(hipMemcpyAsync(ctx.flag_host, ctx.sticky + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        return RTM_OK;
+    }
+    RTM_HIP_CHECK(hipEventRecord(ev.b, stream));
+    unsigned long long c[4];
+    RTM_HIP_CHECK(hipMemcpyAsync(c, ctx.counters, sizeof c, hipMemcpyDeviceToHost, stream));
+    RTM_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    RTM_HIP_CHECK(hipEventElapsedTime(&ms, ev.a, ev.b));
+    stats->samples = (uint64_t)rows * st->width * P.total_samples;
+    stats->casts = c[0];
+    stats->bounces = c[1];
+    stats->draws = c[2];
+    stats->kernel_ms = ms;
+    stats->variant = variant;
+    stats->split = (int32_t)P.split;
+    if (c[3]) {
+        set_last_error(kOverflowText);
+        return RTM_ERR_UNSUPPORTED;
     }
     return RTM_OK;
+}
+
+int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
+                 uint8_t* out8, void* stream_v, rtm_stats* stats) {
+    if (!scene) {
+        set_last_error("null scene");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    int rc = validate(st, nullptr, 0, opt);
+    if (rc == RTM_OK && scene->n > 0x7FFFFFFFull) rc = RTM_ERR_UNSUPPORTED;
+    if (rc != RTM_OK) return rc;
+    if (scene->device != opt->device) {
+        set_last_error("the scene lives on another device than rtm_options.device");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    return render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n),
+                       scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
+}
+
+int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
+                  const rtm_options* opt, double* out64, float* out32, uint8_t* out8,
+                  void* stream_v, rtm_stats* stats) {
+    int rc = validate(st, sp, n, opt);
+    if (rc != RTM_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    RTM_HIP_CHECK(hipSetDevice(opt->device));
+    if (!on_device) {
+        std::shared_ptr<rtm_scene> sc;
+        rc = cached_scene(sp, n, opt->device, &sc);
+        if (rc != RTM_OK) return rc;
+        return render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n), n, opt,
+                           out64, out32, out8, stream, stats);
+    }
+    // device-resident sphere array: flattened on the stream into stream-ordered temporaries, which are
+    // released (hipFreeAsync) behind the render's launches
+    keep_stream_ordered_memory(opt->device);
+    AsyncMem geom, mat, aux;
+    rc = geom.alloc((n ? n : 1) * 4 * sizeof(double), stream);
+    if (rc == RTM_OK) rc = mat.alloc((n + 1) * 8 * sizeof(double), stream);
+    if (rc == RTM_OK) rc = aux.alloc(scene_aux_doubles(n) * sizeof(double), stream);
+    if (rc != RTM_OK) return rc;
+    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, stream>>>(sp, n, geom.as<double>(), mat.as<double>());
+    RTM_HIP_CHECK(hipGetLastError());
+    rc = launch_scene_aux(geom.as<double>(), n, aux.as<double>(), stream);
+    if (rc != RTM_OK) return rc;
+    return render_view(st, scene_view(geom.as<double>(), mat.as<double>(), aux.as<double>(), n), n, opt, out64, out32, out8,
+                       stream, stats);
 }
 
 int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt,
@@ -1724,24 +2039,19 @@ int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rt
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipSetDevice(opt->device));
     const size_t vals = (size_t)output_rows(opt) * st->width * 3;
-    double* d64 = nullptr;
-    float* d32 = nullptr;
-    uint8_t* d8 = nullptr;
+    DevMem d64, d32, d8;
     rtm_stats local;
     if (vals) {
-        if (out64) RTM_HIP_CHECK(hipMalloc((void**)&d64, vals * sizeof(double)));
-        if (out32) RTM_HIP_CHECK(hipMalloc((void**)&d32, vals * sizeof(float)));
-        if (out8) RTM_HIP_CHECK(hipMalloc((void**)&d8, vals));
+        if (out64 && (rc = d64.alloc(vals * sizeof(double))) != RTM_OK) return rc;
+        if (out32 && (rc = d32.alloc(vals * sizeof(float))) != RTM_OK) return rc;
+        if (out8 && (rc = d8.alloc(vals)) != RTM_OK) return rc;
     }
-    rc = render_device(st, sp, n, 0, opt, d64, d32, d8, nullptr, &local);
+    rc = render_device(st, sp, n, 0, opt, d64.as<double>(), d32.as<float>(), d8.as<uint8_t>(), nullptr, &local);
     if (rc == RTM_OK && vals) {
-        if (out64) RTM_HIP_CHECK(hipMemcpy(out64, d64, vals * sizeof(double), hipMemcpyDeviceToHost));
-        if (out32) RTM_HIP_CHECK(hipMemcpy(out32, d32, vals * sizeof(float), hipMemcpyDeviceToHost));
-        if (out8) RTM_HIP_CHECK(hipMemcpy(out8, d8, vals, hipMemcpyDeviceToHost));
+        if (out64) RTM_HIP_CHECK(hipMemcpy(out64, d64.p, vals * sizeof(double), hipMemcpyDeviceToHost));
+        if (out32) RTM_HIP_CHECK(hipMemcpy(out32, d32.p, vals * sizeof(float), hipMemcpyDeviceToHost));
+        if (out8) RTM_HIP_CHECK(hipMemcpy(out8, d8.p, vals, hipMemcpyDeviceToHost));
     }
-    if (d64) (void)hipFree(d64);
-    if (d32) (void)hipFree(d32);
-    if (d8) (void)hipFree(d8);
     if (stats) *stats = local;
     return rc;
 }
@@ -1762,24 +2072,21 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
         return RTM_ERR_INVALID_ARGUMENT;
     }
     if (n_rays == 0) return RTM_OK;
-    RTM_HIP_CHECK(hipSetDevice(opt->device));
-    DeviceScene ds;
-    int rc = ds.upload(sp, n, 0, nullptr);
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, opt->device);
     if (rc != RTM_OK) return rc;
-    double *d_org = nullptr, *d_dir = nullptr, *d_out = nullptr;
-    uint32_t *d_draws = nullptr, *d_casts = nullptr, *d_scratch = nullptr;
+    DevMem d_org, d_dir, d_out, d_draws, d_casts, d_scratch, d_counters, d_trace;
     const size_t vb = n_rays * 3 * sizeof(double);
-    RTM_HIP_CHECK(hipMalloc((void**)&d_org, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_dir, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_out, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_draws, n_rays * 4));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_casts, n_rays * 4));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_scratch, (size_t)RAY_MAX_DEPTH * n_rays * 4));
-    RTM_HIP_CHECK(hipMemcpy(d_org, org, vb, hipMemcpyHostToDevice));
-    RTM_HIP_CHECK(hipMemcpy(d_dir, dir, vb, hipMemcpyHostToDevice));
+    if ((rc = d_org.alloc(vb)) != RTM_OK || (rc = d_dir.alloc(vb)) != RTM_OK || (rc = d_out.alloc(vb)) != RTM_OK ||
+        (rc = d_draws.alloc(n_rays * 4)) != RTM_OK || (rc = d_casts.alloc(n_rays * 4)) != RTM_OK ||
+        (rc = d_scratch.alloc((size_t)RAY_MAX_DEPTH * n_rays * 4)) != RTM_OK || (rc = d_counters.alloc(32)) != RTM_OK)
+        return rc;
+    RTM_HIP_CHECK(hipMemset(d_counters.p, 0, 32));
+    RTM_HIP_CHECK(hipMemcpy(d_org.p, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir.p, dir, vb, hipMemcpyHostToDevice));
     RayBatchParams P;
     std::memset(&P, 0, sizeof P);
-    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    P.scene = scene_view(ds.geom.as<double>(), ds.mat.as<double>(), nullptr, n);
     if (opt->mode & RTM_MODE_HOST_TRIG) {
         const uint32_t* fix = nullptr;
         rc = ensure_trig_fix(opt->device, &fix);
@@ -1797,45 +2104,37 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
             P.key_sample = sm;
         }
     }
-    P.org = d_org;
-    P.dir = d_dir;
+    P.org = d_org.as<double>();
+    P.dir = d_dir.as<double>();
     P.n_rays = n_rays;
-    P.out = d_out;
-    P.out_draws = d_draws;
-    P.out_casts = d_casts;
-    P.scratch = d_scratch;
-    P.counters = ds.counters;
+    P.out = d_out.as<double>();
+    P.out_draws = d_draws.as<uint32_t>();
+    P.out_casts = d_casts.as<uint32_t>();
+    P.scratch = d_scratch.as<uint32_t>();
+    P.counters = d_counters.as<unsigned long long>();
     const char* trace_file = std::getenv("RTM_DEBUG_SEAM_TRACE");  // file that receives ray 0's states
-    double* d_trace = nullptr;
     if (trace_file) {
         P.trace_cap = 256;
-        RTM_HIP_CHECK(hipMalloc((void**)&d_trace, (size_t)P.trace_cap * 6 * sizeof(double)));
-        RTM_HIP_CHECK(hipMemset(d_trace, 0, (size_t)P.trace_cap * 6 * sizeof(double)));
-        P.trace = d_trace;
+        if ((rc = d_trace.alloc((size_t)P.trace_cap * 6 * sizeof(double))) != RTM_OK) return rc;
+        RTM_HIP_CHECK(hipMemset(d_trace.p, 0, (size_t)P.trace_cap * 6 * sizeof(double)));
+        P.trace = d_trace.as<double>();
     }
     path_trace_rays_kernel<<<(unsigned)((n_rays + 63) / 64), 64>>>(P);
-    if (d_trace) {
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipDeviceSynchronize());
+    if (d_trace.p) {
         std::vector<double> h((size_t)P.trace_cap * 6);
-        RTM_HIP_CHECK(hipMemcpy(h.data(), d_trace, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        RTM_HIP_CHECK(hipMemcpy(h.data(), d_trace.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (FILE* f = std::fopen(trace_file, "wb")) {
             std::fwrite(h.data(), sizeof(double), h.size(), f);
             std::fclose(f);
         }
-        (void)hipFree(d_trace);
     }
-    RTM_HIP_CHECK(hipGetLastError());
-    RTM_HIP_CHECK(hipDeviceSynchronize());
     unsigned long long c[4];
-    RTM_HIP_CHECK(hipMemcpy(c, ds.counters, sizeof c, hipMemcpyDeviceToHost));
-    RTM_HIP_CHECK(hipMemcpy(out, d_out, vb, hipMemcpyDeviceToHost));
-    if (out_draws) RTM_HIP_CHECK(hipMemcpy(out_draws, d_draws, n_rays * 4, hipMemcpyDeviceToHost));
-    if (out_casts) RTM_HIP_CHECK(hipMemcpy(out_casts, d_casts, n_rays * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_org);
-    (void)hipFree(d_dir);
-    (void)hipFree(d_out);
-    (void)hipFree(d_draws);
-    (void)hipFree(d_casts);
-    (void)hipFree(d_scratch);
+    RTM_HIP_CHECK(hipMemcpy(c, d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out, d_out.p, vb, hipMemcpyDeviceToHost));
+    if (out_draws) RTM_HIP_CHECK(hipMemcpy(out_draws, d_draws.p, n_rays * 4, hipMemcpyDeviceToHost));
+    if (out_casts) RTM_HIP_CHECK(hipMemcpy(out_casts, d_casts.p, n_rays * 4, hipMemcpyDeviceToHost));
     if (c[3]) {
         set_last_error("a path ran deeper than RAY_MAX_DEPTH");
         return RTM_ERR_UNSUPPORTED;
@@ -1850,32 +2149,26 @@ int intersect_batch(const rtm_sphere* sp, const double* org, const double* dir, 
         return RTM_ERR_INVALID_ARGUMENT;
     }
     if (n == 0) return RTM_OK;
-    DeviceScene ds;
-    int rc = ds.upload(sp, n, 0, nullptr);
+    int device = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, device);
     if (rc != RTM_OK) return rc;
-    double *d_org, *d_dir, *d_t, *d_n;
-    int32_t* d_hit;
+    DevMem d_org, d_dir, d_t, d_n, d_hit;
     const size_t vb = n * 3 * sizeof(double);
-    RTM_HIP_CHECK(hipMalloc((void**)&d_org, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_dir, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_n, vb));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_t, n * sizeof(double)));
-    RTM_HIP_CHECK(hipMalloc((void**)&d_hit, n * sizeof(int32_t)));
-    RTM_HIP_CHECK(hipMemcpy(d_org, org, vb, hipMemcpyHostToDevice));
-    RTM_HIP_CHECK(hipMemcpy(d_dir, dir, vb, hipMemcpyHostToDevice));
-    RTM_HIP_CHECK(hipMemcpy(d_n, out_normal, vb, hipMemcpyHostToDevice));  // untouched where no hit
-    RTM_HIP_CHECK(hipMemcpy(d_t, out_t, n * sizeof(double), hipMemcpyHostToDevice));
-    intersect_pairs_kernel<<<(unsigned)((n + 63) / 64), 64>>>((const double4*)ds.geom, d_org, d_dir,
-                                                              n, mode, d_hit, d_t, d_n);
+    if ((rc = d_org.alloc(vb)) != RTM_OK || (rc = d_dir.alloc(vb)) != RTM_OK || (rc = d_n.alloc(vb)) != RTM_OK ||
+        (rc = d_t.alloc(n * sizeof(double))) != RTM_OK || (rc = d_hit.alloc(n * sizeof(int32_t))) != RTM_OK)
+        return rc;
+    RTM_HIP_CHECK(hipMemcpy(d_org.p, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir.p, dir, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_n.p, out_normal, vb, hipMemcpyHostToDevice));  // untouched where no hit
+    RTM_HIP_CHECK(hipMemcpy(d_t.p, out_t, n * sizeof(double), hipMemcpyHostToDevice));
+    intersect_pairs_kernel<<<(unsigned)((n + 63) / 64), 64>>>((const double4*)ds.geom.p, d_org.as<double>(), d_dir.as<double>(),
+                                                              n, mode, d_hit.as<int32_t>(), d_t.as<double>(), d_n.as<double>());
     RTM_HIP_CHECK(hipGetLastError());
-    RTM_HIP_CHECK(hipMemcpy(out_hit, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    RTM_HIP_CHECK(hipMemcpy(out_t, d_t, n * sizeof(double), hipMemcpyDeviceToHost));
-    RTM_HIP_CHECK(hipMemcpy(out_normal, d_n, vb, hipMemcpyDeviceToHost));
-    (void)hipFree(d_org);
-    (void)hipFree(d_dir);
-    (void)hipFree(d_n);
-    (void)hipFree(d_t);
-    (void)hipFree(d_hit);
+    RTM_HIP_CHECK(hipMemcpy(out_hit, d_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_normal, d_n.p, vb, hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 
@@ -1884,13 +2177,13 @@ int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample
     if (!out) return RTM_ERR_INVALID_ARGUMENT;
     const size_t total = (size_t)n_pixels * n_draws;
     if (!total) return RTM_OK;
-    double* d;
-    RTM_HIP_CHECK(hipMalloc((void**)&d, total * sizeof(double)));
+    DevMem d;
+    const int rc = d.alloc(total * sizeof(double));
+    if (rc != RTM_OK) return rc;
     rng_batch_kernel<<<(n_pixels + 255) / 256, 256>>>(seed_multiplier(seed), pixel0, n_pixels, sample,
-                                                      n_draws, d);
+                                                      n_draws, d.as<double>());
     RTM_HIP_CHECK(hipGetLastError());
-    RTM_HIP_CHECK(hipMemcpy(out, d, total * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    RTM_HIP_CHECK(hipMemcpy(out, d.p, total * sizeof(double), hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 
@@ -1901,25 +2194,23 @@ double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t ind
 int math_probe(int op, const double* a, const double* b, size_t n, double* out) {
     if (!a || !out) return RTM_ERR_INVALID_ARGUMENT;
     if (!n) return RTM_OK;
-    double *da, *db = nullptr, *dout;
-    RTM_HIP_CHECK(hipMalloc((void**)&da, n * 8));
-    RTM_HIP_CHECK(hipMalloc((void**)&dout, n * 8));
-    RTM_HIP_CHECK(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+    DevMem da, db, dout;
+    int rc;
+    if ((rc = da.alloc(n * 8)) != RTM_OK || (rc = dout.alloc(n * 8)) != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipMemcpy(da.p, a, n * 8, hipMemcpyHostToDevice));
     if (b) {
-        RTM_HIP_CHECK(hipMalloc((void**)&db, n * 8));
-        RTM_HIP_CHECK(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+        if ((rc = db.alloc(n * 8)) != RTM_OK) return rc;
+        RTM_HIP_CHECK(hipMemcpy(db.p, b, n * 8, hipMemcpyHostToDevice));
     }
     const uint32_t* fix = nullptr;
     if (op >= 16 && op <= 18) {
-        int rc = ensure_trig_fix(0, &fix);
+        rc = ensure_trig_fix(0, &fix);
         if (rc != RTM_OK) return rc;
     }
-    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da, db, n, dout, fix);
+    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da.as<double>(), b ? db.as<double>() : nullptr, n,
+                                                            dout.as<double>(), fix);
     RTM_HIP_CHECK(hipGetLastError());
-    RTM_HIP_CHECK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    (void)hipFree(dout);
-    if (db) (void)hipFree(db);
+    RTM_HIP_CHECK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 
@@ -1927,14 +2218,16 @@ int math_probe(int op, const double* a, const double* b, size_t n, double* out) 
 // fast/2, 10 shade ref, 11 shade fast.  Returns average cycles per repetition per wave.
 int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
                     double* cycles_per_rep) {
-    DeviceScene ds;
-    int rc = ds.upload(sp, n, 0, nullptr);
+    int device = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, device);
     if (rc != RTM_OK) return rc;
-    double* out;
-    unsigned long long* cyc;
-    RTM_HIP_CHECK(hipMalloc((void**)&out, (size_t)blocks * 64 * 8));
-    RTM_HIP_CHECK(hipMalloc((void**)&cyc, (size_t)blocks * 8));
-    const SceneView sv{(const double4*)ds.geom, ds.mat, (int)n};
+    DevMem d_out, d_cyc;
+    if ((rc = d_out.alloc((size_t)blocks * 64 * 8)) != RTM_OK || (rc = d_cyc.alloc((size_t)blocks * 8)) != RTM_OK) return rc;
+    double* out = d_out.as<double>();
+    unsigned long long* cyc = d_cyc.as<unsigned long long>();
+    const SceneView sv = scene_view(ds.geom.as<double>(), ds.mat.as<double>(), nullptr, n);
     const D3 org0 = D3{0.0, 0.0, -10.0};
     for (int pass = 0; pass < 2; ++pass) {
         const int r = pass ? reps : 4;
@@ -1954,8 +2247,6 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
     double sum = 0;
     for (auto v : h) sum += (double)v;
     *cycles_per_rep = sum / blocks / reps;
-    (void)hipFree(out);
-    (void)hipFree(cyc);
     return RTM_OK;
 }
 
@@ -1965,24 +2256,23 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
                      int32_t* out_id, double* out_t) {
     if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 3 || n_rays > 0x7FFFFFFFull)
         return RTM_ERR_INVALID_ARGUMENT;
-    DeviceScene ds;
-    int rc = ds.upload(sp, n, 0, nullptr);
+    int device = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, device);
     if (rc != RTM_OK) return rc;
     RenderParams P;
     std::memset(&P, 0, sizeof P);
-    P.scene = SceneView{(const double4*)ds.geom, ds.mat, (int)n};
+    P.scene = scene_view(ds.geom.as<double>(), ds.mat.as<double>(), nullptr, n);
     WfState S;
     std::memset(&S, 0, sizeof S);
     const size_t N = n_rays;
     S.npix = (unsigned)N;
     const int n_pad = ((int)n + 7) & ~7;
-    unsigned char* ws = nullptr;
     const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 3 + 4) * 8 + 256;
-    RTM_HIP_CHECK(hipMalloc((void**)&ws, bytes));
-    struct Free {
-        void* p;
-        ~Free() { (void)hipFree(p); }
-    } free_ws{ws};
+    DevMem ws_mem;
+    if ((rc = ws_mem.alloc(bytes)) != RTM_OK) return rc;
+    unsigned char* ws = ws_mem.as<unsigned char>();
     unsigned char* q = ws;
     auto take = [&](size_t b) {
         unsigned char* r = q;
@@ -2037,13 +2327,13 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
 
 int selfcheck(int kind, unsigned long long* mismatches) {
     if (!mismatches) return RTM_ERR_INVALID_ARGUMENT;
-    unsigned long long* d;
-    RTM_HIP_CHECK(hipMalloc((void**)&d, 8));
-    RTM_HIP_CHECK(hipMemset(d, 0, 8));
-    selfcheck_kernel<<<4096, 256>>>(kind, d);
+    DevMem d;
+    const int rc = d.alloc(8);
+    if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipMemset(d.p, 0, 8));
+    selfcheck_kernel<<<4096, 256>>>(kind, d.as<unsigned long long>());
     RTM_HIP_CHECK(hipGetLastError());
-    RTM_HIP_CHECK(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    RTM_HIP_CHECK(hipMemcpy(mismatches, d.p, 8, hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 

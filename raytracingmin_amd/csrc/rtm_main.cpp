@@ -2,8 +2,9 @@
 //
 //   rtm_cli [-?] [-json <file>] [-sampleJson]            (the reference's flags, same defaults)
 //           [--width N] [--height N] [--samples N] [--superSamples N] [--spp N]
-//           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM] [--host-trig]
-//           [--gpus N] [--virtual-strips N]      (interleaved 8-row bands over N GPUs + one RCCL gather)
+//           [--mode literal|repaired] [--max-bounces N] [--seed N] [--device N] [--out STEM] [--device-trig]
+//           [--gpus N] [--virtual-strips N] [--force-rccl]   (interleaved 8-row bands over N GPUs + one RCCL gather)
+//           [--dump-f32 FILE]                    (the gathered float3 buffer, raw little-endian floats)
 //
 // Flow of the reference: pick the JSON (default settingData.json), create the sample JSON when it
 // does not exist, load, render, write <stem>.jpg (quality 60) and <stem>.bmp with stem "result".
@@ -32,15 +33,18 @@ static void usage() {
         "--spp N : samples = N / superSamples^2\n"
         "--mode literal|repaired (default repaired), --max-bounces N (default -1 = unlimited)\n"
         "--seed N, --device N, --out STEM (default result)\n"
-        "--host-trig : sin/cos exactly as this host's libm returns them (bit-identical to a CPU run of the reference even\n"
-        "              where deep paths amplify one-ulp differences; ~2 %% slower)\n"
-        "--gpus N : interleaved 8-row bands over N GPUs of this node, one RCCL gather; --virtual-strips N : N parts on one GPU\n");
+        "--device-trig : the device's own sin/cos instead of this host's libm values (default: host values, bit-identical\n"
+        "              to a CPU run of the reference even where deep paths amplify one-ulp differences; device-trig is ~2 %% faster)\n"
+        "--gpus N : interleaved 8-row bands over N GPUs of this node, one RCCL gather of the float3 buffer;\n"
+        "--force-rccl : take the RCCL exchange with --gpus 1 too; --virtual-strips N : N parts on one GPU, no RCCL\n"
+        "--dump-f32 FILE : write the float3 accumulation buffer (raw floats, row-major RGB)\n");
 }
 
 int main(int argc, char* argv[]) {
     std::string json_file = "settingData.json", stem = "result";
     int width = 0, height = 0, samples = 0, super_samples = 0, spp = 0;
-    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0, host_trig = 0;
+    int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0, host_trig = 1, force_rccl = 0;
+    std::string dump_f32;
     unsigned long long seed = 0x5EED;
     for (int i = 1; i < argc; ++i) {
         const std::string c = argv[i];
@@ -68,6 +72,9 @@ int main(int argc, char* argv[]) {
         else if (c == "--gpus") next_int(gpus);
         else if (c == "--virtual-strips") next_int(virtual_strips);
         else if (c == "--host-trig") host_trig = 1;
+        else if (c == "--device-trig") host_trig = 0;
+        else if (c == "--force-rccl") force_rccl = 1;
+        else if (c == "--dump-f32" && i + 1 < argc) dump_f32 = argv[++i];
         else if (c == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 0);
         else if (c == "--out" && i + 1 < argc) stem = argv[++i];
         else if (c == "--mode" && i + 1 < argc) {
@@ -117,25 +124,35 @@ int main(int argc, char* argv[]) {
 
     const size_t vals = (size_t)st.width * st.height * 3;
     std::vector<uint8_t> rgb8(vals);
+    std::vector<float> rgb32(dump_f32.empty() ? 0 : vals);
     rtm_stats stats;
-    if (gpus > 1 || virtual_strips > 0) {
+    if (gpus > 1 || virtual_strips > 0 || force_rccl) {
         int have = 0;
         if (rtm_device_count(&have) != RTM_OK || have < gpus) {
             std::fprintf(stderr, "--gpus %d requested, %d HIP device(s) present\n", gpus, have);
             return 1;
         }
         std::string err;
-        rc = rtm_node_render_u8(&st, spheres.data(), n, &opt, gpus, virtual_strips, rgb8.data(), &stats, err);
+        rc = rtm_node_render(&st, spheres.data(), n, &opt, gpus, virtual_strips, force_rccl,
+                             rgb32.empty() ? nullptr : rgb32.data(), rgb8.data(), &stats, err);
         if (rc != RTM_OK) {
             std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), err.c_str());
             return 1;
         }
     } else {
-        rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, nullptr, rgb8.data(), &stats);
+        rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, rgb32.empty() ? nullptr : rgb32.data(), rgb8.data(), &stats);
         if (rc != RTM_OK) {
             std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), rtm_last_error_detail());
             return 1;
         }
+    }
+    if (!dump_f32.empty()) {
+        FILE* f = std::fopen(dump_f32.c_str(), "wb");
+        if (!f || std::fwrite(rgb32.data(), sizeof(float), vals, f) != vals) {
+            std::fprintf(stderr, "cannot write %s\n", dump_f32.c_str());
+            return 1;
+        }
+        std::fclose(f);
     }
     std::printf("%d x %d, %llu samples, %.3f casts/sample, kernel %.3f ms, %.1f Msamples/s\n", st.width,
                 st.height, (unsigned long long)stats.samples,

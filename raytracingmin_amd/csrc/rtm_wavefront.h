@@ -50,6 +50,10 @@ __device__ __forceinline__ void wf_pixel_xy(const RenderParams& P, unsigned p, i
 __global__ __launch_bounds__(256) void wf_init_kernel(const RenderParams P, const WfState S) {
     const unsigned p = blockIdx.x * 256 + threadIdx.x;
     if (p >= S.npix) return;
+    if (p == 0) {  // every pixel starts active; the other list is empty
+        S.n_active[0] = S.npix;
+        S.n_active[1] = 0u;
+    }
     int x, y;
     wf_pixel_xy(P, p, x, y);
     const D3 pd = primary_dir(P, x, y, 1, 1);

@@ -106,7 +106,8 @@ class StripRenderer:
     step).  layout "bands": interleaved 8-row bands (default); "strips": contiguous strips."""
 
     def __init__(self, data, rank=0, world=1, device=0, mode="repaired", max_bounces=-1,
-                 seed=0x5EED, variant=0, want="f32", rows=None, layout="bands", host_trig=False):
+                 seed=0x5EED, variant=0, want="f32", rows=None, layout="bands", host_trig=True,
+                 force_collective=False):
         from .renderer import Renderer
         if layout not in ("bands", "strips"):
             raise ValueError(f"unknown layout {layout!r}")
@@ -116,6 +117,9 @@ class StripRenderer:
         self.strips = [(lo + b, lo + e) for b, e in partition_rows(hi - lo, world)]
         self.rows = self.strips[rank]
         self.want = want
+        # world == 1 normally skips the gather; force_collective sends the frame through the process
+        # group anyway (the one-rank RCCL rehearsal of the N-rank step)
+        self.force_collective = bool(force_collective)
         self.renderer = Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, device=device,
                                  variant=variant, host_trig=host_trig)
         self.image = None  # assembled frame on rank 0 after step()
@@ -134,7 +138,7 @@ class StripRenderer:
         if events is not None:
             events[1].record()
         local = out[self.want]
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             self.image = local
         elif self.layout == "bands":
             self.image = gather_bands(local, self.range[0], self.range[1], self.rank, self.world)

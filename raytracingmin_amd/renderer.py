@@ -20,7 +20,10 @@ from .settings import SettingData
 
 class Renderer:
     def __init__(self, data: SettingData, mode="repaired", max_bounces=-1, seed=0x5EED, device=0,
-                 variant=0, host_trig=False):
+                 variant=0, host_trig=True):
+        # host_trig (default): sin/cos of src/Renderer.cpp:93-94 as the HOST's libm returns them, so a
+        # render agrees with a CPU run of the reference bit for bit even on scenes that amplify one-ulp
+        # differences over many bounces; host_trig=False is the labelled ~2 % faster device-trig row
         self.data = data  # the reference keeps a reference to the caller's SettingData
         self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0)
         self.max_bounces = int(max_bounces)
@@ -29,6 +32,39 @@ class Renderer:
         self.variant = int(variant)
         self.image = np.zeros((data.height, data.width, 3), dtype=np.float64)  # src/Renderer.cpp:21
         self.stats = None
+        self._scene = None      # rtm_scene* on self.device (made on first use, kept for the renderer's life)
+        self._scene_key = None
+
+    # ---- the scene on the device: flattened and uploaded once per renderer -------------------
+    def _scene_handle(self):
+        """rtm_scene_create once; made again only when the object list was replaced or resized
+        (call invalidate() after editing spheres in place)."""
+        key = (id(self.data.object), len(self.data.object))
+        if self._scene is None or key != self._scene_key:
+            self.invalidate()
+            arr, n = self.data.spheres_c()
+            h = C.c_void_p()
+            _lib.check(_lib.lib().rtm_scene_create(arr, n, 0, self.device, C.byref(h)), "rtm_scene_create")
+            self._scene, self._scene_key = h, key
+        return self._scene
+
+    def invalidate(self):
+        if self._scene is not None:
+            _lib.lib().rtm_scene_destroy(self._scene)
+            self._scene = None
+
+    def __del__(self):
+        try:
+            self.invalidate()
+        except Exception:
+            pass
+
+    def stream_status(self, stream=None):
+        """rtm_stream_status: raises RtmError if a stats-less render on the stream was truncated."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        hip_stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().rtm_stream_status(self.device, C.c_void_p(hip_stream)), "rtm_stream_status")
 
     def _options(self, row_begin, row_end, band=None):
         o = rtm_options()
@@ -59,13 +95,13 @@ class Renderer:
             out["f32"] = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
         if "u8" in want:
             out["u8"] = torch.empty((rows, W, 3), dtype=torch.uint8, device=dev)
-        st, arr, n = self.data.to_c()
+        st = self.data.settings_c()
         s = rtm_stats()
         hip_stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out and rows > 0 else None
-        _lib.check(_lib.lib().rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), ptr("f64"),
-                                                ptr("f32"), ptr("u8"), C.c_void_p(hip_stream),
-                                                C.byref(s) if stats else None), "rtm_render_device")
+        _lib.check(_lib.lib().rtm_render_scene(C.byref(st), self._scene_handle(), C.byref(opt), ptr("f64"),
+                                               ptr("f32"), ptr("u8"), C.c_void_p(hip_stream),
+                                               C.byref(s) if stats else None), "rtm_render_scene")
         return out, (s.as_dict() if stats else None)
 
     # ---- host-buffer render (the blocking C entry point) ------------------------------------
@@ -104,7 +140,7 @@ class Renderer:
 
 # ---- seams below the renderer, for parity tests --------------------------------------------------
 def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_bounces=-1,
-                       seed=0x5EED, device=0, host_trig=False):
+                       seed=0x5EED, device=0, host_trig=True):
     """png::PathTracing (src/Renderer.cpp:57-117) for n rays; ray i draws from stream (seed, i, 0)."""
     org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
     direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)

@@ -55,6 +55,11 @@ class SettingData:  # src/SettingData.h:47-51
 
     # ---- flattening to / from the C ABI structs
     def to_c(self):
+        st = self.settings_c()
+        arr, n = self.spheres_c()
+        return st, arr, n
+
+    def settings_c(self):
         st = rtm_settings()
         st.width, st.height = int(self.width), int(self.height)
         st.samples, st.super_samples = int(self.samples), int(self.superSamples)
@@ -65,6 +70,9 @@ class SettingData:  # src/SettingData.h:47-51
         for k, v in enumerate(self.camera.upVec):
             st.camera.up[k] = float(v)
         st.camera.fov = float(self.camera.fov)
+        return st
+
+    def spheres_c(self):
         n = len(self.object)
         arr = (rtm_sphere * max(n, 1))()
         for i, o in enumerate(self.object):
@@ -75,7 +83,7 @@ class SettingData:  # src/SettingData.h:47-51
             for k, v in enumerate(o.m_material.emission):
                 arr[i].emission[k] = float(v)
             arr[i].radius = float(o.m_size)
-        return st, arr, n
+        return arr, n
 
     @staticmethod
     def from_c(st, arr, n):

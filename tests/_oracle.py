@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+SCENES = os.path.join(ROOT, "scenes")
 
 MODE_LITERAL, MODE_REPAIRED = 0, 1
 
@@ -80,6 +80,9 @@ def lib():
         L.rtmo_render.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t,
                                   C.POINTER(Options), C.c_void_p, C.POINTER(Counters), C.c_int,
                                   C.c_int]
+        L.rtmo_render_pixels.restype = C.c_int
+        L.rtmo_render_pixels.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t, C.POINTER(Options),
+                                         C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Counters), C.c_int]
         L.rtmo_sample_radiance.restype = None
         L.rtmo_sample_radiance.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t,
                                            C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -169,6 +172,18 @@ def render(st, spheres, n, opt, threads=0, structure=0, want_counters=True):
                            C.byref(cnt) if want_counters else None, threads, structure)
     if rc != 0:
         raise RuntimeError(f"rtmo_render failed: {rc}")
+    return out, cnt.as_dict()
+
+
+def render_pixels(st, spheres, n, opt, xy, threads=0):
+    """The oracle's image values of the listed pixels: xy = [(x, y), ...] -> (len(xy), 3) float64."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((xy.shape[0], 3), dtype=np.float64)
+    cnt = Counters()
+    rc = lib().rtmo_render_pixels(C.byref(st), spheres, n, C.byref(opt), xy.ctypes.data, xy.shape[0],
+                                  out.ctypes.data, C.byref(cnt), threads)
+    if rc != 0:
+        raise RuntimeError(f"rtmo_render_pixels failed: {rc}")
     return out, cnt.as_dict()
 
 

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "rtm.h")).read()
+def _declared_symbols(header="rtm.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rtm_[a-z0-9_]+)\s*\(", text)))
 
@@ -18,13 +18,25 @@ def _declared_symbols():
 def test_header_symbols_are_exported_and_bound():
     from raytracingmin_amd import _lib
     names = _declared_symbols()
-    assert len(names) >= 19
+    assert len(names) >= 24
     raw = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/rtm.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().rtm_abi_version() == 2
+    assert _lib.lib().rtm_abi_version() == _lib.ABI_VERSION == 3
+
+
+def test_exported_symbols_are_exactly_the_two_headers():
+    """librtm_hip.so exports the drop-in boundary (include/rtm.h) plus the test/diagnostic hooks of
+    include/rtm_debug.h and no other rtm_* C symbol."""
+    import subprocess
+    from raytracingmin_amd import _lib
+    debug = _declared_symbols("rtm_debug.h")
+    assert sorted(_lib.DEBUG_SIGNATURES) == debug and all(n.startswith("rtm_debug_") for n in debug)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if re.search(r" T rtm_[a-z0-9_]+$", l))
+    assert exported == sorted(_declared_symbols() + debug)
 
 
 def test_struct_layouts_match_header():
@@ -33,7 +45,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.rtm_sphere) == 80
     assert C.sizeof(_lib.rtm_settings) == 96
     assert C.sizeof(_lib.rtm_options) == 40
-    assert C.sizeof(_lib.rtm_stats) == 40
+    assert C.sizeof(_lib.rtm_stats) == 48
     # the oracle's view of the same PODs
     import _oracle
     assert C.sizeof(_oracle.Sphere) == 80 and C.sizeof(_oracle.Settings) == 96

@@ -46,6 +46,29 @@ def test_band_rows_partition_the_range_and_match_the_library(lo, hi, world):
     assert max(sizes) - min(sizes) <= 8
 
 
+def _collect(procs, q, n_items, timeout=120):
+    """n_items results from the workers' queue; fails (instead of hanging) when a worker dies first."""
+    import queue as _q
+    import time
+    items, deadline = [], time.time() + timeout
+    try:
+        while len(items) < n_items:
+            try:
+                items.append(q.get(timeout=1.0))
+            except _q.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"a worker exited with {dead} before delivering its result"
+                assert time.time() < deadline, "workers timed out"
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return items
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -84,16 +107,12 @@ def _worker(rank, world, port, height, width, q):
 def test_gather_strips_and_bands_gloo(world, height):
     width = 13
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, height, width, q)) for r in range(world)]
     for p in procs:
         p.start()
-    img = q.get()
-    img_bands = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    img, img_bands = _collect(procs, q, 2)
     r, c, ch = np.meshgrid(np.arange(height), np.arange(width), np.arange(3), indexing="ij")
     assert np.array_equal(img, (r * 10000 + c * 10 + ch).astype(np.float32))
     assert np.array_equal(img_bands, (r * 10000 + c * 10 + ch).astype(np.float32))

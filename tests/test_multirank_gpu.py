@@ -19,6 +19,29 @@ def _free_port():
     return p
 
 
+def _collect(procs, q, n_items, timeout=240):
+    """n_items results from the workers' queue; fails (instead of hanging) when a worker dies first."""
+    import queue as _q
+    import time
+    items, deadline = [], time.time() + timeout
+    try:
+        while len(items) < n_items:
+            try:
+                items.append(q.get(timeout=1.0))
+            except _q.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"a worker exited with {dead} before delivering its result"
+                assert time.time() < deadline, "workers timed out"
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0, p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return items
+
+
 def _worker(rank, world, port, scene, dims, q):
     import torch
     import torch.distributed as dist
@@ -53,18 +76,67 @@ def test_strips_from_n_ranks_equal_single_rank_frame(world, dims):
     import raytracingmin_amd as rtm
     scene = _oracle.scene_path("cornellBoxSetting.json")
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, scene, dims, q)) for r in range(world)]
     for p in procs:
         p.start()
-    img = q.get()
-    img_bands = q.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    img, img_bands = _collect(procs, q, 2)
     data = rtm.LoadData(scene).data
     data.width, data.height, data.samples, data.superSamples = dims
     full, _ = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED).render_rows(want=("f64",))
     assert np.array_equal(img.view(np.uint64), full["f64"].view(np.uint64))
     assert np.array_equal(img_bands.view(np.uint64), full["f64"].view(np.uint64))
+
+
+def _rccl_worker(port, scene, dims, q):
+    """ONE rank, backend nccl (= RCCL): the N-rank step with the collective forced — communicator init,
+    dist.gather on device tensors, the de-interleave on the root."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import raytracingmin_amd as rtm
+        from raytracingmin_amd.distributed import StripRenderer, gather_bands, gather_strips
+        assert dist.get_backend() == "nccl"
+        data = rtm.LoadData(scene).data
+        data.width, data.height, data.samples, data.superSamples = dims
+        out = {}
+        for layout in ("bands", "strips"):
+            sr = StripRenderer(data, rank=0, world=1, device=0, mode="repaired", max_bounces=8, seed=0x5EED,
+                               want="f32", layout=layout, force_collective=True)
+            sr.step()
+            assert sr.image.is_cuda
+            out[layout] = sr.image.cpu().numpy()
+        # the collectives on their own, on device tensors that are not a render's output
+        t = torch.arange(45 * 7 * 3, dtype=torch.float32, device="cuda").reshape(45, 7, 3)
+        g = gather_bands(t, 0, 45, 0, 1)
+        g2 = gather_strips(t, [(0, 45)], 0, 1)
+        torch.cuda.synchronize()
+        q.put((out["bands"], out["strips"], bool(torch.equal(g, t)) and bool(torch.equal(g2, t))))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_process_group_runs_the_gather():
+    """torch.distributed over RCCL has run on this box: world size 1, the step's gather forced."""
+    import torch.multiprocessing as mp
+    import _oracle
+    import raytracingmin_amd as rtm
+    scene = _oracle.scene_path("cornellBoxSetting.json")
+    dims = (88, 45, 2, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(_free_port(), scene, dims, q))]
+    procs[0].start()
+    (bands, strips, ok), = _collect(procs, q, 1)
+    assert ok
+    data = rtm.LoadData(scene).data
+    data.width, data.height, data.samples, data.superSamples = dims
+    full, _ = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED).render_rows(want=("f32",))
+    assert np.array_equal(bands.view(np.uint32), full["f32"].view(np.uint32))
+    assert np.array_equal(strips.view(np.uint32), full["f32"].view(np.uint32))
