@@ -83,6 +83,38 @@ __device__ __forceinline__ double negate_where(LaneMask k, double x) {
     return __hiloint2double(__double2hiint(x) ^ (int)(k.m & 0x80000000u), __double2loint(x));
 }
 
+// k ? a : b with the condition as a wave mask in an SGPR pair (what v_cmp / ballot produce) and the VOP3
+// encoding spelled out: hipcc's own a ? b : c on doubles becomes back-to-back v_cndmask_b32_e32 reading VCC,
+// the slow form above (13 vs 3 cycles each in the microbenchmark).
+__device__ __forceinline__ uint32_t sel_u32_mask(unsigned long long m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double sel_f64_mask(unsigned long long m, double a, double b) {
+    const uint32_t hi = sel_u32_mask(m, (uint32_t)__double2hiint(a), (uint32_t)__double2hiint(b));
+    const uint32_t lo = sel_u32_mask(m, (uint32_t)__double2loint(a), (uint32_t)__double2loint(b));
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// k ? index : old for a small non-negative index: as an inline constant of the VOP3 encoding when the
+// compiler knows it (the unrolled tail chunk of a scene under 8 spheres), else from a register.
+__device__ __forceinline__ int sel_index_mask(unsigned long long m, int index, int old) {
+    int r;
+#define RTM_SEL_INDEX_CASE(i) \
+    case i: asm("v_cndmask_b32_e64 %0, %1, " #i ", %2" : "=v"(r) : "v"(old), "s"(m)); return r;
+    if (__builtin_constant_p(index)) {
+        switch (index) {
+            RTM_SEL_INDEX_CASE(0) RTM_SEL_INDEX_CASE(1) RTM_SEL_INDEX_CASE(2) RTM_SEL_INDEX_CASE(3)
+            RTM_SEL_INDEX_CASE(4) RTM_SEL_INDEX_CASE(5) RTM_SEL_INDEX_CASE(6) RTM_SEL_INDEX_CASE(7)
+            default: break;
+        }
+    }
+#undef RTM_SEL_INDEX_CASE
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(old), "v"(index), "s"(m));
+    return r;
+}
+
 // ---- sin and cos of r in [0, 2^30) without branches ----
 // The same operation sequence as the small-argument path of ROCm's ocml sincos (three-part pi/2
 // Cody-Waite reduction with FMA, then the (hi, lo) sin/cos kernels), written out so that the

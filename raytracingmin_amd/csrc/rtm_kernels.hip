@@ -382,18 +382,38 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     };
 
     (void)fold_pass;
+    // wave-level counters of the DEFER loop (scalar registers): every live lane casts once per trip
+    unsigned w_casts = 0, w_bounces = 0, w_draws = 0;
     if constexpr (DEFER) {
-        // wave-uniform loop: a lane that has finished its samples idles here, because fold_pass needs
-        // all 64 lanes whatever their own state
-        while (__builtin_amdgcn_ballot_w64(n < n_end) != 0) {
-            bool ended = false, fifo_full = false;
-            if (n < n_end) {
-                D3 term;
-                int hit_id;
-                bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push,
-                                                 trig, &hit_id);
-                if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
-                if (!cont) {
+        // Wave-uniform loop: fold_pass needs all 64 lanes whatever their own state, so a lane that has finished
+        // its samples cannot leave.  It does not idle either: it keeps tracing (samples beyond its range, results
+        // discarded — `live` gates the queue, the counters and nothing else), which costs nothing — the lanes are
+        // there anyway — and keeps the whole body free of a per-lane "am I still in range" region, i.e. of the
+        // exec-mask bookkeeping and register copies hipcc generates around one (-14 VALU per trip).
+        for (;;) {
+            // lane masks as scalars (SGPR pairs straight from the compares): every count below is a popcount
+            const unsigned long long m_live = __builtin_amdgcn_ballot_w64(n < n_end);
+            if (m_live == 0ull) break;
+            const bool live = n < n_end;
+            bool fifo_full = false;
+            D3 term;
+            int hit_id;
+            const int depth_before = depth;
+            PathCounters unused = {0, 0, 0};
+            bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
+                                             trig, &hit_id);
+            if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
+            // counters (src/Renderer.cpp has none; rtm_stats): one cast per live lane, one draw for the RR test of a
+            // hit below the depth cap, two more and a bounce when the path continues
+            const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_live;
+            unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_live;
+            if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
+            const unsigned n_cont = (unsigned)__builtin_popcountll(m_cont);
+            w_casts += (unsigned)__builtin_popcountll(m_live);
+            w_draws += (unsigned)__builtin_popcountll(m_drew) + 2u * n_cont;
+            w_bounces += n_cont;
+            if (!cont) {
+                if (live) {
                     // queue this path end: ring position = tail + rank among the lanes ending now
                     const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
@@ -404,7 +424,6 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
                                            (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
                         fq_in1[pos] = rec_w1[lane];
-                        if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
                     } else {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
                     }
@@ -412,29 +431,30 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
                     fq_pend[lane] = pend;
                     fifo_full = pend >= 8u || (PACKL && depth > 16);  // pooled levels must be folded before reuse
-                    ended = true;
-                    // next sample of this pixel (src/Renderer.cpp:236-239)
-                    ++n;
-                    if (--left_in_sub == 0) {
-                        left_in_sub = P.S;
-                        if (n < n_end) {
-                            const int sub = (int)(n / (unsigned)P.S);
-                            int px, py;
-                            pixel_xy(px, py);
-                            pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
-                            park[3 * 64 + lane] = pdir.x;
-                            park[4 * 64 + lane] = pdir.y;
-                            park[5 * 64 + lane] = pdir.z;
-                        }
-                    }
-                    org = P.cam_org;
-                    dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
-                    depth = 0;
-                    recq = packed8_empty(P.scene.n);
-                    rng = rng_open(pkey, n);
                 }
+                if constexpr (PACKL) {
+                    if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
+                }
+                // next sample of this pixel (src/Renderer.cpp:236-239); a lane past its range stays at n_end, so that
+                // "n - pending" remains the sample index of its queued path ends (fold_pass, SPLIT)
+                n += live ? 1u : 0u;
+                if (--left_in_sub == 0) {
+                    left_in_sub = P.S;
+                    const int sub = (int)(n / (unsigned)P.S);
+                    int px, py;
+                    pixel_xy(px, py);
+                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                    park[3 * 64 + lane] = pdir.x;
+                    park[4 * 64 + lane] = pdir.y;
+                    park[5 * 64 + lane] = pdir.z;
+                }
+                org = P.cam_org;
+                dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
+                depth = 0;
+                recq = packed8_empty(P.scene.n);
+                rng = rng_open(pkey, n);
             }
-            const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));
+            const unsigned added = (unsigned)__builtin_popcountll(m_live & ~m_cont);
             if (added != 0u) {
                 fq_tail = (fq_tail + added) & (kFoldRing - 1);
                 fq_count += added;
@@ -547,9 +567,17 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
     }
     if (P.counters) {
-        wave_add_counter(P.counters + 0, pc.casts);
-        wave_add_counter(P.counters + 1, pc.bounces);
-        wave_add_counter(P.counters + 2, pc.draws);
+        if constexpr (DEFER) {
+            if (lane == 0) {
+                atomicAdd(P.counters + 0, (unsigned long long)w_casts);
+                atomicAdd(P.counters + 1, (unsigned long long)w_bounces);
+                atomicAdd(P.counters + 2, (unsigned long long)w_draws);
+            }
+        } else {
+            wave_add_counter(P.counters + 0, pc.casts);
+            wave_add_counter(P.counters + 1, pc.bounces);
+            wave_add_counter(P.counters + 2, pc.draws);
+        }
         if (stack.overflow) atomicOr(P.counters + 3, 1ull);
     }
 }
@@ -1404,6 +1432,19 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
         if (P.max_bounces >= 0 && P.max_bounces <= 8 && P.scene.n < 256) {  // ids and the identity index in a byte
+            if constexpr (DEFER && UNROLL == -8) {
+                // scenes under 8 spheres (every shipped scene): the instantiation for exactly n spheres
+                switch (P.scene.n) {
+#define RTM_EXACT_N(k)                                                                                     \
+    case k:                                                                                                \
+        render_tiles_kernel<M, LDS_TAB, -100 - k, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>           \
+            <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);                                              \
+        return;
+                    RTM_EXACT_N(1) RTM_EXACT_N(2) RTM_EXACT_N(3) RTM_EXACT_N(4) RTM_EXACT_N(5) RTM_EXACT_N(6) RTM_EXACT_N(7)
+#undef RTM_EXACT_N
+                    default: break;
+                }
+            }
             if constexpr (DEFER)
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>
                     <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);

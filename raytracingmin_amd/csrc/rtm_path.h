@@ -7,6 +7,17 @@
 #include <cfloat>
 #include <type_traits>
 
+// A/B switches of the round-2 instruction trimming (profiles/r2/ab_*.txt); all on by default.
+#ifndef RTM_OPT_GUARD
+#define RTM_OPT_GUARD 1
+#endif
+#ifndef RTM_OPT_SEL64
+#define RTM_OPT_SEL64 1
+#endif
+#ifndef RTM_OPT_TRIGLOAD
+#define RTM_OPT_TRIGLOAD 1
+#endif
+
 #include "../../include/rtm.h"
 #include "rtm_device.h"
 
@@ -109,9 +120,21 @@ struct MathFast {
     // D4 = +0 has a real hit at t = b).
     template <int K>
     static __device__ __forceinline__ void sqrt64_batch_hit(const double (&x)[K], double (&out)[K]) {
+#if RTM_OPT_GUARD
+        // "every high word >= 0x10000000" as ONE compare of their unsigned minimum (v_min3_u32): the K
+        // compare / select / shift / or steps hipcc makes of the && chain were ~25 instructions per cast
+        unsigned lowest = (unsigned)__double2hiint(x[0]);
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const unsigned h = (unsigned)__double2hiint(x[k]);
+            lowest = h < lowest ? h : lowest;
+        }
+        const bool ok = lowest >= 0x10000000u;
+#else
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < K; ++k) ok = ok && ((unsigned)__double2hiint(x[k]) >= 0x10000000u);
+#endif
         if (__builtin_amdgcn_ballot_w64(!ok) != 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
@@ -198,15 +221,57 @@ struct MathSpec {
         bad = bad || !sqrtf_fast_ok(len2);
         return (double)sqrtf_fast(len2);
     }
+#if RTM_OPT_GUARD
+    // The three divisions x / m, m = (double)sqrtf((float)(x.x)) of a Normalize, with the guard reduced to what
+    // can actually go wrong.  sqrtf_fast_ok(len2) already pins m to [2^-48, 2^64) — always "moderate" — and
+    // every |x_i| to < 2^64, and a NaN or infinite component makes len2 NaN or infinite, which it rejects.
+    // What is left is a component so small that v_div_scale would have rescaled the division (|x_i| below
+    // about 2^-900): caught by ONE unsigned compare of the smallest high word of the SQUARES, which the
+    // caller has at hand (x_i^2 < 2^-800 means |x_i| < 2^-400, the bound `moderate` uses).  An exactly
+    // zero component (square +0) trips it too and sends the wave down the compiler's path: correct, and
+    // for directions that went through a random bounce a measure-zero event.
+    __device__ __forceinline__ D3 div3_by_magnitude(D3 a, double sx, double sy, double sz, float len2) {
+        unsigned lo = (unsigned)__double2hiint(sx);
+        const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
+        lo = hy < lo ? hy : lo;
+        lo = hz < lo ? hz : lo;
+        bad = bad | !sqrtf_fast_ok(len2) | (lo < 0x0DF00000u);  // 2^-800
+        const double y = (double)sqrtf_fast(len2);
+        double r = __builtin_amdgcn_rcp(y);
+        double e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        auto one = [&](double x) {
+            const double q = x * r;
+            const double rem = __builtin_fma(-y, q, x);
+            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+        };
+        return D3{one(a.x), one(a.y), one(a.z)};
+    }
+    __device__ __forceinline__ D3 normalize(D3 a) {
+        const double sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
+        return div3_by_magnitude(a, sx, sy, sz, (float)(sx + sy + sz));
+    }
+#else
     __device__ __forceinline__ D3 normalize(D3 a) { return div3(a, magnitude_spec(a)); }
+#endif
     // Normalize of a vector whose y component is a (signed) zero — Cross((0,1,0), w) for finite w:
     // y*y adds +0 to the squared length and +-0 / m is the same +-0, so only x and z are divided.
     // Anything else in y (NaN from a non-finite w) trips `bad`.
     __device__ __forceinline__ D3 normalize_y0(D3 a) {
+#if RTM_OPT_GUARD
+        const double sx = a.x * a.x, sz = a.z * a.z;
+        const float len2 = (float)(sx + sz);
+        const unsigned hx = (unsigned)__double2hiint(sx), hz = (unsigned)__double2hiint(sz);
+        bad = bad | !sqrtf_fast_ok(len2) | !(a.y == 0.0) | ((hx < hz ? hx : hz) < 0x0DF00000u);  // see div3_by_magnitude
+        const double y = (double)sqrtf_fast(len2);
+#else
         const float len2 = (float)(a.x * a.x + a.z * a.z);
         bad = bad || !sqrtf_fast_ok(len2) || !(a.y == 0.0);
         const double y = (double)sqrtf_fast(len2);
         bad = bad || !(MathFast::moderate(a.x) && MathFast::moderate(a.z));  // y: a normal float here
+#endif
         double r = __builtin_amdgcn_rcp(y);
         double e = __builtin_fma(-y, r, 1.0);
         r = __builtin_fma(r, e, r);
@@ -225,6 +290,19 @@ struct MathSpec {
     // per-sphere constant `rinv` (both precomputed with the same instruction sequence).  Taken only
     // when every active lane is in that case; otherwise the general Normalize runs.
     __device__ __forceinline__ D3 normalize_on_sphere(D3 dv, double ms, double rinv, float r2f) {
+#if RTM_OPT_GUARD
+        const double sx = dv.x * dv.x, sy = dv.y * dv.y, sz = dv.z * dv.z;
+        const float len2f = (float)(sx + sy + sz);
+        const bool canon = (len2f == r2f) && (rinv == rinv);
+        if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3_by_magnitude(dv, sx, sy, sz, len2f);
+        // canonical: |dv|^2 rounds to the float r*r of a sphere whose refined reciprocal exists (rinv is NaN when
+        // ms is outside the exact range), so only a tiny component remains to be excluded
+        unsigned lo = (unsigned)__double2hiint(sx);
+        const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
+        lo = hy < lo ? hy : lo;
+        lo = hz < lo ? hz : lo;
+        bad = bad | (lo < 0x0DF00000u);
+#else
         const float len2f = (float)(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
         const bool canon = (len2f == r2f) && (rinv == rinv);
         if (__builtin_amdgcn_ballot_w64(!canon) != 0) {
@@ -232,6 +310,7 @@ struct MathSpec {
             return div3(dv, (double)sqrtf_fast(len2f));
         }
         bad = bad || !(MathFast::moderate(dv.x) && MathFast::moderate(dv.y) && MathFast::moderate(dv.z));
+#endif
         auto one = [&](double x) {
             const double q = x * rinv;
             const double rem = __builtin_fma(-ms, q, x);
@@ -308,15 +387,25 @@ struct SceneView {
 // the whole domain and the +-1 ulp differences kept in a table (two signed 2-bit fields per r1).
 // `rng` is the stream right after the draws of r1 and r2: r1's draw is recomputed from it rather than
 // kept live, so the default path (no table) carries nothing extra.
-__device__ __forceinline__ void apply_trig_fix(const uint32_t* __restrict__ fix, const RngStream& rng, double& sn,
-                                               double& cs) {
+// Two halves, so that the table word can be requested as soon as r1's draw is known and used ~150
+// instructions later, after the sincos it corrects (the load's latency then overlaps the block's arithmetic).
+struct TrigFixWord {
+    uint32_t word;
+    int off;
+};
+__device__ __forceinline__ TrigFixWord trig_fix_load(const uint32_t* __restrict__ fix, const RngStream& rng) {
     const uint32_t k = mix32((rng.ctr - 2u * 0x9E3779B9u) ^ rng.k1) >> 9;
-    const uint32_t word = fix[k >> 3];
-    const int off = (int)(k & 7u) * 4;
-    const long long ds = (long long)(int)__builtin_amdgcn_sbfe(word, (unsigned)off, 2u);      // sign-extended
-    const long long dc = (long long)(int)__builtin_amdgcn_sbfe(word, (unsigned)off + 2u, 2u);
+    return TrigFixWord{fix[k >> 3], (int)(k & 7u) * 4};
+}
+__device__ __forceinline__ void trig_fix_apply(const TrigFixWord w, double& sn, double& cs) {
+    const long long ds = (long long)(int)__builtin_amdgcn_sbfe(w.word, (unsigned)w.off, 2u);      // sign-extended
+    const long long dc = (long long)(int)__builtin_amdgcn_sbfe(w.word, (unsigned)w.off + 2u, 2u);
     sn = __longlong_as_double(__double_as_longlong(sn) + ds);
     cs = __longlong_as_double(__double_as_longlong(cs) + dc);
+}
+__device__ __forceinline__ void apply_trig_fix(const uint32_t* __restrict__ fix, const RngStream& rng, double& sn,
+                                               double& cs) {
+    trig_fix_apply(trig_fix_load(fix, rng), sn, cs);
 }
 
 // Wave-uniform geometry fetch.  The tables are never written while a render kernel runs, but the
@@ -424,6 +513,26 @@ __device__ __forceinline__ void sphere_update(const double4 g, const D3 org, con
     hit_object = accept ? i : hit_object;
 }
 
+// The acceptance update of one sphere (select-only form, see sphere_update): t = t1 > 0.001 ? t1 : t2;
+// accept = t < dis && !(t < 1e-5f); the nearest hit and its index follow.
+__device__ __forceinline__ void accept_update(const double b, const double sq, const int index, double& dis,
+                                              int& hit_object) {
+    const double t1 = b - sq, t2 = b + sq;
+#if RTM_OPT_SEL64
+    // masks straight from the compares (SGPR pairs); NaN t: "t < dis" is false, so nothing is accepted
+    const double t = sel_f64_mask(__builtin_amdgcn_ballot_w64(t1 > 0.001), t1, t2);
+    const unsigned long long accept =
+        __builtin_amdgcn_ballot_w64(t < dis) & ~__builtin_amdgcn_ballot_w64(t < (double)1e-5f);
+    dis = sel_f64_mask(accept, t, dis);
+    hit_object = sel_index_mask(accept, index, hit_object);
+#else
+    const double t = (t1 > 0.001) ? t1 : t2;
+    const bool accept = (t < dis) && !(t < (double)1e-5f);
+    dis = accept ? t : dis;
+    hit_object = accept ? index : hit_object;
+#endif
+}
+
 // K consecutive spheres starting at i0 as ONE basic block: K independent Intersect evaluations
 // (independent dependency chains the scheduler interleaves), their square roots behind a single
 // wave-uniform guard, then the K acceptance updates in index order (strict <: the lowest index still
@@ -464,13 +573,7 @@ __device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int 
     }
     M::template sqrt64_batch_hit<K>(D4, sq);                       // :205 (D4 < 0 gives NaN: no hit)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
-        const double t = (t1 > 0.001) ? t1 : t2;
-        const bool accept = (t < dis) && !(t < (double)1e-5f);
-        dis = accept ? t : dis;
-        hit_object = accept ? i0 + k : hit_object;
-    }
+    for (int k = 0; k < K; ++k) accept_update(b[k], sq[k], i0 + k, dis, hit_object);
 }
 // spheres whose geometry is fetched together inside a chunk (profiles/r1: 7 at once 202.7 ms, 4: 195.6,
 // 3: 194.5, 2: 194.2 ms on the same box; SGPR spills 44 -> 10)
@@ -505,13 +608,7 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
         else
             M::template sqrt64_batch_hit<K>(D4, sq);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
-            const double t = (t1 > 0.001) ? t1 : t2;
-            const bool accept = (t < dis) && !(t < (double)1e-5f);
-            dis = accept ? t : dis;
-            hit_object = accept ? i0 + k : hit_object;
-        }
+        for (int k = 0; k < K; ++k) accept_update(b[k], sq[k], i0 + k, dis, hit_object);
         return;
     }
     double4 g[K];
@@ -539,7 +636,13 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
     } else {
         // UNROLL < 0: the caller guarantees n < -UNROLL, so there is no full chunk and the loop is not even
         // compiled (it is what sets the kernel's register high-water mark)
-        constexpr int U = UNROLL < 0 ? -UNROLL : UNROLL;
+        if constexpr (UNROLL <= -101 && UNROLL >= -107) {
+            // the caller guarantees n == -UNROLL - 100: the scene is ONE exact chunk, no switch, no other sizes
+            // compiled in (scenes under 8 spheres; the launcher picks the instantiation)
+            sphere_chunk<M, -UNROLL - 100>(sc, 0, org, dir, dis, hit_object);
+            return hit_object;
+        }
+        constexpr int U = UNROLL <= -101 ? 8 : (UNROLL < 0 ? -UNROLL : UNROLL);
         static_assert(U == 8 || U == 4, "chunks of 8 or 4 plus an exact tail");
         int i0 = 0;
         if constexpr (UNROLL > 0) {
@@ -564,15 +667,22 @@ struct PathCounters {
 };
 
 // The part of one PathTracing invocation (src/Renderer.cpp:57-117) after the nearest-hit loop:
-// `id`/`dis` are that loop's result.  Returns true when the path continues (org/dir/depth updated,
-// hit id pushed through `push`); false when it ended with `term` = the value the deepest invocation
-// returned.  `m` is a math policy object (MathRefI, MathFastI or MathSpec).
-template <class MI, class Scene, typename PushFn>
-__device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const int id, const double dis,
-                                                const int mode, const int max_bounces, D3& org, D3& dir,
-                                                int& depth, RngStream& rng, D3& term, PathCounters& pc,
-                                                PushFn push) {
-    pc.casts++;
+// `id`/`dis` are that loop's result.  PURE: the caller's ray, depth and RNG stream come in by value and the
+// bounce goes out through `out`, which is written only when the path continues (returns true); when it ended,
+// `term` is the value the deepest invocation returned.  Keeping the inputs untouched is what lets the
+// speculative form below re-run the block from the same operands without saving them first — and it keeps
+// hipcc from copying the whole ray at the entry of every nested region (24 v_mov per trip before).
+// `m` is a math policy object (MathRefI, MathFastI or MathSpec).
+struct ShadeOut {
+    D3 org, dir;     // the bounced ray (src/Renderer.cpp:108)
+    uint32_t ctr;    // RNG counter after this invocation's draws
+    int draws;       // 0, 1 or 3
+};
+template <class MI, class Scene>
+__device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const int id, const double dis,
+                                                const int mode, const int max_bounces, const D3 org, const D3 dir,
+                                                const int depth, RngStream rng, D3& term, ShadeOut& out) {
+    out.draws = 0;
     if (id < 0) {  // :116
         term = d3(0, 0, 0);
         return false;
@@ -582,7 +692,7 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
         term = emission;
         return false;
     }
-    pc.draws++;
+    out.draws = 1;
     if (!(rng_next(rng) <= sc.kd(id))) {  // :78, kd() is a float widened to double
         term = emission;                  // :112
         return false;
@@ -600,9 +710,13 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
     // :82-83  w = Dot(n, d) < 0 ? n : n * -1.0  (multiplying by -1.0 flips the sign bit, exactly)
     const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));
     const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
-    pc.draws += 2;
+    out.draws = 3;
     const double r1 = 6.283185307179586 * rng_next(rng);  // :88  (2*PI folded)
     const double r2 = rng_next(rng);                      // :89
+#if RTM_OPT_TRIGLOAD
+    TrigFixWord fixw{0u, 0};
+    if (sc.v.trig_fix) fixw = trig_fix_load(sc.v.trig_fix, rng);  // wave-uniform; consumed after the sincos
+#endif
     const double r2s = m.sqrt64(r2);                      // :90
     // :96-101 — one Normalize on the selected cross product (same values as the two-armed if)
     const bool use_y = fabs(w.x) > (double)FLT_MIN;
@@ -618,14 +732,39 @@ __device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const in
     const D3 v = cross(w, u);  // :102
     double sn, cs;
     m.sincos_r1(r1, sn, cs);
+#if RTM_OPT_TRIGLOAD
+    if (sc.v.trig_fix) trig_fix_apply(fixw, sn, cs);  // wave-uniform
+#else
     if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);  // wave-uniform
-    const D3 nd = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
-    push(depth, id);
-    depth++;
-    pc.bounces++;
-    org = hit_point;
-    dir = nd;
+#endif
+    out.dir = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
+    out.org = hit_point;
+    out.ctr = rng.ctr;
     return true;
+}
+
+// The classic interface on top of it: returns true when the path continues (org/dir/depth/rng updated, hit id
+// pushed through `push`); false when it ended with `term`.  Counters as the reference would count them.
+template <class MI, class Scene, typename PushFn>
+__device__ __forceinline__ bool path_shade_with(MI& m, const Scene& sc, const int id, const double dis,
+                                                const int mode, const int max_bounces, D3& org, D3& dir,
+                                                int& depth, RngStream& rng, D3& term, PathCounters& pc,
+                                                PushFn push) {
+    ShadeOut o;
+    const bool cont = path_shade_core(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
+    pc.casts++;
+    pc.draws += (unsigned)o.draws;
+    if (cont) {
+        push(depth, id);
+        depth++;
+        pc.bounces++;
+        org = o.org;
+        dir = o.dir;
+        rng.ctr = o.ctr;
+    } else {
+        rng.ctr += (unsigned)o.draws * 0x9E3779B9u;
+    }
+    return cont;
 }
 
 // Static-policy form (M = MathRef or MathFast).
@@ -639,33 +778,34 @@ __device__ __forceinline__ bool path_shade(const Scene& sc, const int id, const 
 
 // Speculative form: the whole shading block with MathSpec (one basic block), then ONE check; if any
 // lane's operand was outside MathSpec's exact range the block is re-run with the compiler's math
-// from the saved inputs (push is idempotent, counters and RNG are restored).
+// from the same inputs (path_shade_core leaves them alone).  The hit record is pushed once, after the
+// attempt that counts.
 template <class Scene, typename PushFn>
 __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, const double dis, const int mode,
                                                 const int max_bounces, D3& org, D3& dir, int& depth,
                                                 RngStream& rng, D3& term, PathCounters& pc, PushFn push,
                                                 const double* trig_lds = nullptr) {
-    const D3 org0 = org, dir0 = dir;
-    const int depth0 = depth;
-    const RngStream rng0 = rng;
-    const PathCounters pc0 = pc;
-    // the hit record is pushed once, after the attempt that counts: a packed record register is not
-    // idempotent under a repeated push (a continuing path pushes exactly (depth before, id))
-    auto no_push = [](int, int) {};
+    ShadeOut o;
     MathSpec m;
     m.trig_lds = trig_lds;
-    bool cont = path_shade_with(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, no_push);
+    bool cont = path_shade_core(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
-        org = org0;
-        dir = dir0;
-        depth = depth0;
-        rng = rng0;
-        pc = pc0;
         MathRefI r;
         r.trig_lds = trig_lds;
-        cont = path_shade_with(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, no_push);
+        cont = path_shade_core(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     }
-    if (cont) push(depth0, id);
+    pc.casts++;
+    pc.draws += (unsigned)o.draws;
+    if (cont) {
+        push(depth, id);
+        depth++;
+        pc.bounces++;
+        org = o.org;
+        dir = o.dir;
+        rng.ctr = o.ctr;
+    } else {
+        rng.ctr += (unsigned)o.draws * 0x9E3779B9u;
+    }
     return cont;
 }
 

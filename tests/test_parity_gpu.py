@@ -915,7 +915,7 @@ def test_config2_full_frame_vs_oracle(rtm, oracle, max_bounces):
 def test_config4_band_parts_vs_oracle(rtm, oracle):
     """BASELINE configs[3]: Cornell box 3840x2160 @ 4096 spp (SS 4 x S 256), max 8 bounces, dealt out to
     eight ranks in interleaved 8-row bands exactly as bench.py --gpus 8 does (band=(8, r): one launch per
-    rank, sample split on).  Per part: two rows against the oracle at the full 4096 spp.  All parts:
+    rank).  Per part: two rows against the oracle at the full 4096 spp.  All parts:
     they reassemble to the frame one launch renders (bit for bit), counters add up."""
     from raytracingmin_amd.distributed import band_row_index
     scene = oracle.scene_path("cornellBoxSetting.json")
@@ -930,7 +930,8 @@ def test_config4_band_parts_vs_oracle(rtm, oracle):
     for rank in range(8):
         part, ps = r.render_rows_device(0, H, want=("f64",), band=(8, rank))
         rows = band_row_index(0, H, 8, rank)
-        assert part["f64"].shape == (len(rows), W, 3) and ps["split"] > 1
+        assert part["f64"].shape == (len(rows), W, 3)
+        # (no sample split here: 16 320 tiles x 2 048 deferred samples of terms would be 51 GB, over the 24 GB budget)
         frame[rows] = part["f64"].cpu().numpy()
         for k in total:
             total[k] += ps[k]
