@@ -108,6 +108,24 @@ def other_configs(rtm, cfg, device, host_trig):
         out[name] = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 5,
                      "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
                      "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"]}
+    # SEPARATELY LABELLED row: the headline frame with the primary hit of a sub-pixel computed once
+    # for its S samples (variant 15) — same image and counters, less work per sample than the reference does
+    data.width, data.height, data.samples, data.superSamples = cfg["width"], cfg["height"], cfg["samples"], cfg["super_samples"]
+    r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+                     host_trig=host_trig, variant=15)
+    r.render_rows_device(want=("f32",), stats=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r.render_rows_device(want=("f32",), stats=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    _, st = r.render_rows_device(want=("f32",), stats=True)
+    out["LABELLED_headline_frame_with_primary_hit_reuse"] = {
+        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+        "kernel_ms": st["kernel_ms"], "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
+        "note": "not comparable with the headline value or the CPU baseline: one nearest-hit search per sub-pixel "
+                "instead of one per sample for the primary ray (the reference repeats it, src/Renderer.cpp:224-238)"}
     stress = rtm.make_stress_scene(n=100_000, seed=12345)
     stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
     r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)

@@ -215,14 +215,23 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //           kd^16 of the paths) in the pooled global stack.  A queue entry carries both words and the pool
 //           slot; a lane that queues a path deeper than 16 forces a pass, so its slot is free again
 //           before its next path can reach level 16.
+//   REUSE   (with DEFER + PACK8; variant 15, a SEPARATELY LABELLED row, never the default) the S samples of a
+//           sub-pixel share one primary ray (no jitter, src/Renderer.cpp:224-232), so its nearest hit is computed
+//           once per sub-pixel and reused: a lane whose path ended restarts at "primary hit known" in the SAME
+//           trip and joins the shading block with the lanes that bounced.  Every trip is then one nearest-hit
+//           search and one bounce for every lane (no idle lanes in either block) and a sample costs C - 1 trips
+//           instead of C.  Same image, same counters (a reused primary hit still counts as the cast the reference
+//           performs); different work per sample than the reference, hence the label.
 constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
 constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
 constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
 
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
-          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false>
+          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false,
+          bool REUSE = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
+    static_assert(!REUSE || (DEFER && PACK8 && !SPLIT), "primary-hit reuse rides on the deferred fold with packed records");
     static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -384,7 +393,108 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     (void)fold_pass;
     // wave-level counters of the DEFER loop (scalar registers): every live lane casts once per trip
     unsigned w_casts = 0, w_bounces = 0, w_draws = 0;
-    if constexpr (DEFER) {
+    if constexpr (DEFER && REUSE) {
+        // ---- primary-hit reuse (see REUSE above) ----
+        // the primary hit of the lane's current sub-pixel: recomputed when the sub-pixel changes (once per S samples)
+        double pdis;
+        int pid = nearest_hit<M, UNROLL>(sc, P.cam_org, pdir, pdis);
+        int id = pid;       // the hit the lane is about to classify ...
+        double dis = pdis;  // ... for its ray (org, dir) at `depth`; every lane starts at its first sample's primary hit
+        bool have_fresh_rays = false;
+        for (;;) {
+            const unsigned long long m_live0 = __builtin_amdgcn_ballot_w64(n < n_end);
+            if (m_live0 == 0ull) break;
+            if (have_fresh_rays) id = nearest_hit<M, UNROLL>(sc, org, dir, dis);  // wave-uniform: one search per lane and trip
+            // ---- classify until every live lane holds a hit whose path continues (src/Renderer.cpp:74-78, :112, :116) ----
+            bool settled = !(n < n_end);  // a lane past its range: nothing to classify; it shades a dummy below
+            for (;;) {
+                const bool pending = !settled;
+                const unsigned long long m_pend = __builtin_amdgcn_ballot_w64(pending);
+                if (m_pend == 0ull) break;
+                bool ends = false, drew = false, fifo_full = false;
+                if (pending) {
+                    const bool capped = P.max_bounces >= 0 && depth >= P.max_bounces;
+                    drew = id >= 0 && !capped;
+                    bool rr_pass = false;
+                    if (drew) rr_pass = rng_next(rng) <= sc.kd(id);  // :78
+                    ends = !rr_pass;
+                    settled = rr_pass;
+                    if (ends) {
+                        // queue this path end: ring position = tail + rank among the lanes ending now
+                        const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
+                        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
+                        const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
+                        const unsigned term_id = (unsigned)(id < 0 ? P.scene.n : id);
+                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
+                        const unsigned pend = fq_pend[lane] + 1u;
+                        fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
+                        fq_pend[lane] = pend;
+                        fifo_full = pend >= 8u;
+                        // next sample of this pixel: its primary ray and — new — its primary hit
+                        ++n;
+                        if (--left_in_sub == 0) {
+                            left_in_sub = P.S;
+                            if (n < n_end) {
+                                const int sub = (int)(n / (unsigned)P.S);
+                                int px, py;
+                                pixel_xy(px, py);
+                                pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                                park[3 * 64 + lane] = pdir.x;
+                                park[4 * 64 + lane] = pdir.y;
+                                park[5 * 64 + lane] = pdir.z;
+                                pid = nearest_hit<M, UNROLL>(sc, P.cam_org, pdir, pdis);  // once per S samples
+                            }
+                        }
+                        org = P.cam_org;
+                        dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
+                        depth = 0;
+                        recq = packed8_empty(P.scene.n);
+                        rng = rng_open(pkey, n);
+                        id = pid;
+                        dis = pdis;
+                        settled = !(n < n_end);  // out of samples: done (shades a dummy below)
+                    }
+                }
+                // counters: every classified hit is one PathTracing invocation of the reference
+                w_casts += (unsigned)__builtin_popcountll(m_pend);
+                w_draws += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(drew));
+                const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ends));
+                if (added != 0u) {
+                    fq_tail = (fq_tail + added) & (kFoldRing - 1);
+                    fq_count += added;
+                    const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;
+                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass();
+                }
+            }
+            // ---- bounce: every lane holds a hit that passed the roulette (lanes out of samples: a dummy) ----
+            const bool live = n < n_end;
+            const unsigned n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
+            if (n_live == 0u) break;
+            const int sid = id < 0 ? 0 : id;  // dummies may hold a miss; the scene has at least one sphere here
+            ShadeOut o;
+            {
+                MathSpec m;
+                m.trig_lds = trig;
+                path_bounce_core(m, sc, sid, dis, P.mode, org, dir, rng, o);
+                if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
+                    MathRefI r;
+                    r.trig_lds = trig;
+                    path_bounce_core(r, sc, sid, dis, P.mode, org, dir, rng, o);
+                }
+            }
+            w_draws += 2u * n_live;
+            w_bounces += n_live;
+            push(depth, sid);
+            depth++;
+            org = o.org;
+            dir = o.dir;
+            rng.ctr = o.ctr;
+            have_fresh_rays = true;
+        }
+        while (fq_count > 0u) fold_pass();
+    }
+    if constexpr (DEFER && !REUSE) {
         // Wave-uniform loop: fold_pass needs all 64 lanes whatever their own state, so a lane that has finished
         // its samples cannot leave.  It does not idle either: it keeps tracing (samples beyond its range, results
         // discarded — `live` gates the queue, the counters and nothing else), which costs nothing — the lanes are
@@ -1362,9 +1472,11 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "wavefront-scalar-scene", "wavefront-scalar-scene-reject",
                                       "wavefront-scalar-scene-reject-f32",
                                       "fast-math-lds-tables-chunk8-park-pack8-immediate-fold",
-                                      "fast-math-global-scene-chunk8-park-pack8"};
+                                      "fast-math-global-scene-chunk8-park-pack8",
+                                      ("LABELLED-primary-hit-reuse (one nearest-hit search per sub-pixel for its S primary rays; "
+                                       "not the reference's work per sample)")};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
@@ -1506,6 +1618,15 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         } else {
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }
+    } else if (variant == kVariantPrimaryReuse) {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
+        const size_t lds = lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                           kFoldQueueBytes + debug_lds_pad();
+        if (n < 8)
+            render_tiles_kernel<MathFast, true, -8, uint8_t, 16, 4, true, false, true, false, true, false, true>
+                <<<grid, 64, lds, stream>>>(P);
+        else
+            render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, false, true, false, true>
+                <<<grid, 64, lds, stream>>>(P);
     } else if (variant == kVariantGlobalDefer && n < 256) {
         if (P.split > 1) {
             launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
@@ -1929,6 +2050,11 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                   n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
     else if (variant == kVariantSplit)
         variant = kVariantFastLds;
+    if (variant == kVariantPrimaryReuse &&
+        !(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && P.max_bounces >= 0 && P.max_bounces <= 8)) {
+        set_last_error("variant 15 (primary-hit reuse) serves scenes of 1..24 spheres with 0 <= max_bounces <= 8");
+        return RTM_ERR_UNSUPPORTED;
+    }
     // the sample split rides on the packed-record kernels (explicit variant 2 never splits)
     if (n < 256 && (opt->variant == kVariantAuto || force_split) &&
         (variant == kVariantFastLds || variant == kVariantGlobalDefer)) {

@@ -704,6 +704,12 @@ struct ShadeOut {
     uint32_t ctr;    // RNG counter after this invocation's draws
     int draws;       // 0, 1 or 3
 };
+// The bounce itself (src/Renderer.cpp:79-108): everything after the Russian-roulette test has passed.  `rng` is
+// the stream right after the RR draw; always continues.
+template <class MI, class Scene>
+__device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const int id, const double dis, const int mode,
+                                                 const D3 org, const D3 dir, RngStream rng, ShadeOut& out);
+
 template <class MI, class Scene>
 __device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const int id, const double dis,
                                                 const int mode, const int max_bounces, const D3 org, const D3 dir,
@@ -723,6 +729,13 @@ __device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const in
         term = emission;                  // :112
         return false;
     }
+    path_bounce_core(m, sc, id, dis, mode, org, dir, rng, out);
+    return true;
+}
+
+template <class MI, class Scene>
+__device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const int id, const double dis, const int mode,
+                                                 const D3 org, const D3 dir, RngStream rng, ShadeOut& out) {
     const D3 hit_point = dir * dis + org;  // :79
     // D2: in literal mode the caller's normal stays (0,0,0); repaired: src/SettingData.cpp:214-215
     D3 normal = d3(0, 0, 0);
@@ -774,7 +787,7 @@ __device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const in
                                         ((uz * cs) * r2s + (vz * sn) * r2s) + w.z * s1));  // :103-107
             out.org = hit_point;
             out.ctr = rng.ctr;
-            return true;
+            return;
         }
     }
 #endif
@@ -797,7 +810,6 @@ __device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const in
     out.dir = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
     out.org = hit_point;
     out.ctr = rng.ctr;
-    return true;
 }
 
 // The classic interface on top of it: returns true when the path continues (org/dir/depth/rng updated, hit id

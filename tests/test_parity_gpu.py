@@ -33,6 +33,14 @@ def rtm():
     return m
 
 
+def _variants(rtm, data, max_bounces):
+    """Kernel variants that serve this scene: all of them, except that the labelled primary-hit-reuse row
+    (variant 15) is built for scenes of 1..24 spheres with a depth cap of at most 8."""
+    n = len(data.object)
+    return [v for v in range(rtm.lib().rtm_num_variants())
+            if v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8)]
+
+
 def _probe(rtm, op, a, b=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     out = np.empty_like(a)
@@ -427,7 +435,9 @@ def test_render_literal_matches_reference_golden_hashes(rtm, oracle):
                                                     ("cornellBoxSetting.json", "repaired", -1),
                                                     ("cornellBoxSetting.json", "literal", -1),
                                                     ("simpleSetting2.json", "repaired", -1),
-                                                    ("settingData.json", "repaired", 3)])
+                                                    ("settingData.json", "repaired", 3),
+                                                    ("cornellBoxSetting.json", "literal", 8),
+                                                    ("simpleSetting1.json", "repaired", 0)])
 def test_kernel_variants_are_bit_identical(rtm, oracle, scene, mode, max_bounces):
     """Every kernel variant (reference math / fast math, global / LDS scene tables, non-power-of-
     two and power-of-two sample counts) produces the same bits and the same counters."""
@@ -436,7 +446,7 @@ def test_kernel_variants_are_bit_identical(rtm, oracle, scene, mode, max_bounces
         data.width, data.height, data.samples, data.superSamples = w, h, s, ss
         names = [rtm.lib().rtm_variant_name(v).decode() for v in range(rtm.lib().rtm_num_variants())]
         ref, ref_stats = _gpu_image(rtm, data, mode, max_bounces, 0x5EED, want=("f64", "u8"), variant=1)
-        for v in range(len(names)):
+        for v in _variants(rtm, data, max_bounces):
             out, st = _gpu_image(rtm, data, mode, max_bounces, 0x5EED, want=("f64", "u8"), variant=v)
             assert np.array_equal(out["f64"].view(np.uint64), ref["f64"].view(np.uint64)), names[v]
             assert np.array_equal(out["u8"], ref["u8"])
@@ -460,7 +470,7 @@ def test_stress_scene_vs_oracle(rtm, oracle, n, w, h, s):
     data, ost, oarr = _stress(rtm, oracle, n, w, h, s)
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=5, height=h))
     base = None
-    for v in range(rtm.lib().rtm_num_variants()):
+    for v in _variants(rtm, data, 8):
         out, stats = _gpu_image(rtm, data, "repaired", 8, 5, want=("f64",), variant=v)
         err = float(np.max(np.abs(out["f64"] - ref)))
         print(f"stress n={n} variant {v}: max pixel delta {err:.3e}, casts/sample "
@@ -487,7 +497,7 @@ def test_coincident_spheres_lowest_index_wins(rtm, oracle):
     ost = oracle.Settings.from_buffer_copy(bytes(st))
     oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=6, seed=3, height=24))
-    for v in range(rtm.lib().rtm_num_variants()):
+    for v in _variants(rtm, data, 6):
         out, stats = _gpu_image(rtm, data, "repaired", 6, 3, want=("f64",), variant=v)
         assert float(np.max(np.abs(out["f64"] - ref))) <= PIXEL_TOL
         assert stats["casts"] == cnt["casts"]
@@ -509,7 +519,7 @@ def test_deep_paths_use_record_pool(rtm, oracle):
     oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=11, height=data.height))
     assert cnt["max_depth"] > 80  # well past the 64 LDS levels
-    for v in range(rtm.lib().rtm_num_variants()):
+    for v in _variants(rtm, data, -1):
         out, stats = _gpu_image(rtm, data, "repaired", -1, 11, want=("f64",), variant=v)
         assert float(np.max(np.abs(out["f64"] - ref))) <= PIXEL_TOL
         assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"])
@@ -1062,3 +1072,26 @@ def test_two_host_threads_share_a_stream(rtm, oracle):
     for j in range(len(jobs)):
         for k in range(6):
             assert _bits_equal(got[j][k], want[j]), (j, k)
+
+
+def test_primary_hit_reuse_row_is_bit_identical_and_rejects_what_it_does_not_serve(rtm, oracle):
+    """Variant 15 — the labelled row that computes a sub-pixel's primary hit once for its S samples — gives the
+    oracle's image and counters (a reused primary hit still counts as the cast the reference performs), on a
+    frame with many samples per sub-pixel and on one with S = 1 (nothing to reuse); unlimited depth and big
+    scenes are refused, not silently served by another kernel."""
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    for (w, h, s, ss, mb) in ((160, 96, 32, 2, 8), (64, 40, 1, 3, 5), (40, 24, 7, 1, 0)):
+        data = rtm.LoadData(scene).data
+        data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+        out, st = _gpu_image(rtm, data, "repaired", mb, 77, want=("f64",), variant=15)
+        ost, oarr, n = oracle.load_scene(scene, width=w, height=h, samples=s, super_samples=ss)
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=mb, seed=77, height=h))
+        assert _bits_equal(out["f64"], ref)
+        assert {k: st[k] for k in ("samples", "casts", "bounces", "draws")} == \
+               {k: cnt[k] for k in ("samples", "casts", "bounces", "draws")}
+        assert st["variant"] == 15
+    data = rtm.LoadData(scene).data
+    data.width, data.height, data.samples, data.superSamples = 32, 16, 2, 1
+    with pytest.raises(rtm.RtmError) as e:
+        _gpu_image(rtm, data, "repaired", -1, 1, want=("f64",), variant=15)
+    assert e.value.status == -8
