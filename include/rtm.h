@@ -67,6 +67,31 @@ typedef struct rtm_sphere {
     float _pad;
 } rtm_sphere;
 
+/* Any object of png::SettingData::object — src/SettingData.h:18-42 — for scenes that are not all spheres.
+ * type 1: png::SphereObject (position = centre, size = radius as a float, like m_size).
+ * type 2: png::PlaneObject(position, up, target, width, mat) — src/SettingData.cpp:235-242.  The reference
+ *   constructs m_normal = Normalize(target - position) and m_right = Normalize(Cross(m_normal, up)) * 0.5 * width
+ *   but leaves Intersect unfinished (it falls off its end, :243-246) and never builds one (the loader only
+ *   knows type 1).  This build completes it as the finite square the constructor describes — centre
+ *   `position`, side `width`, spanned by m_right and Cross(m_right, m_normal):
+ *       dn = Dot(m_normal, dir);           if |dn| < FLT_EPSILON: no hit            (the reference's own line, :244)
+ *       t  = Dot(m_normal, position - org) / dn;      if !(t > 0.001): no hit       (the sphere's near threshold)
+ *       d  = org + dir * t - position;     if |Dot(d, m_right)| > Dot(m_right, m_right)
+ *                                          or |Dot(d, m_upv)|   > Dot(m_upv, m_upv): no hit
+ *       out_dis = t; out_normal = m_normal  (the caller orients it against the ray, src/Renderer.cpp:82-83)
+ *   A BUILD-DEFINED semantics: the reference has none to match; oracle and device agree bit for bit. */
+enum { RTM_OBJECT_SPHERE = 1, RTM_OBJECT_PLANE = 2 };
+typedef struct rtm_object {
+    int32_t type;        /* RTM_OBJECT_*                                                       */
+    float size;          /* sphere radius (float, SphereObject::m_size); unused for planes     */
+    double position[3];  /* sphere centre / plane centre                                        */
+    double color[3];
+    double emission[3];
+    double up[3];        /* plane only                                                          */
+    double target[3];    /* plane only: the normal points from position towards target          */
+    double width;        /* plane only: side of the square (a double, like the constructor's)   */
+} rtm_object;
+
 /* png::SettingData minus the object vector — src/SettingData.h:47-51. */
 typedef struct rtm_settings {
     int32_t width, height, samples, super_samples;
@@ -138,6 +163,10 @@ int rtm_release_scratch(int device);
  * array may be freed at once.  A scene belongs to one device. */
 int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
                      rtm_scene** out_scene);
+/* The same for a list of objects of any type (spheres and planes in the reference's vector order, which
+ * decides ties: the lowest index wins).  Scenes that contain a plane are rendered by the general per-object
+ * kernel (variant 1); rtm_options.variant must be 0 or 1 for them.  HOST pointer. */
+int rtm_scene_create_objects(const rtm_object* objects, size_t n_objects, int device, rtm_scene** out_scene);
 int rtm_scene_destroy(rtm_scene* scene);
 size_t rtm_scene_size(const rtm_scene* scene);
 
@@ -196,6 +225,10 @@ int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_
 int rtm_intersect_batch(const rtm_sphere* spheres, const double* org, const double* dir,
                         size_t n, int mode, int32_t* out_hit, double* out_t, double* out_normal);
 
+/* The same seam for objects of any type (rtm_object): pair i tests ray i against object i. */
+int rtm_intersect_objects_batch(const rtm_object* objects, const double* org, const double* dir, size_t n, int mode,
+                                int32_t* out_hit, double* out_t, double* out_normal);
+
 /* ---- the build-defined RNG (reference seeds std::mt19937 from random_device:
  * src/Renderer.cpp:210-213, so there is no reference stream to match).  Host-side evaluation of
  * draw `index` of stream (seed, pixel, sample); device side must agree (rtm_rng_batch). */
@@ -213,6 +246,13 @@ int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* sett
                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
 int rtm_scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* settings,
                          rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
+/* The same loaders for files that may hold planes ("00 objectType": 2 with "00 position", "01 size" = width,
+ * "03 up", "04 target", "02 material" — a build-defined extension of the schema; the sphere-only loaders
+ * above reject such a file with RTM_ERR_INVALID_SCENE). */
+int rtm_scene_load_json_objects(const char* path, int literal_loader, rtm_settings* settings,
+                                rtm_object* objects, size_t capacity, size_t* n_objects);
+int rtm_scene_parse_json_objects(const char* text, size_t len, int literal_loader, rtm_settings* settings,
+                                 rtm_object* objects, size_t capacity, size_t* n_objects);
 /* LoadData::SaveSampleJson (src/SettingData.cpp:14-24,100-127): 960x540, samples 10, SS 4. */
 int rtm_scene_save_sample_json(const char* path);
 /* Stress scene of BASELINE config 5: SplitMix64(seed), n spheres. */

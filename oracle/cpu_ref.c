@@ -122,12 +122,56 @@ static double libc_rand_generator(void* ctx) {
 }
 
 typedef struct pt_env {
-    const rtm_sphere* spheres;
+    const rtm_sphere* spheres; /* geometry of spheres; materials of every object */
     size_t n;
     int mode;
     int max_bounces;
     rtmo_counters* c;
+    const rtm_object* objects; /* NULL: all spheres.  Else parallel to `spheres`: type and plane data */
 } pt_env;
+
+/* png::PlaneObject — constructor src/SettingData.cpp:235-242 restated; Intersect COMPLETED by this build
+ * (the reference's falls off its end after its first line, :243-246): include/rtm.h, rtm_object. */
+typedef struct plane_data {
+    v3 position, normal, right, upv;
+    double rr, uu;
+} plane_data;
+static plane_data plane_make(const rtm_object* o) {
+    plane_data p;
+    p.position = v3_from(o->position);
+    p.normal = normalize3(v3_sub(v3_from(o->target), p.position));                             /* :240 */
+    p.right = v3_scale(v3_scale(normalize3(cross3(p.normal, v3_from(o->up))), 0.5), o->width); /* :241 */
+    p.upv = cross3(p.right, p.normal); /* build-defined: the in-plane direction across m_right */
+    p.rr = dot3(p.right, p.right);
+    p.uu = dot3(p.upv, p.upv);
+    return p;
+}
+static int intersect_plane(const rtm_object* o, v3 org, v3 dir, int mode, double* out_t, v3* out_normal) {
+    const plane_data p = plane_make(o);
+    const double dn = dot3(p.normal, dir);
+    if (fabs(dn) < (double)FLT_EPSILON) return 0; /* :244, the reference's only line */
+    const double t = dot3(p.normal, v3_sub(p.position, org)) / dn;
+    if (!(t > 0.001)) return 0; /* the near threshold of SphereObject::Intersect's t1 (:212) */
+    const v3 d = v3_sub(v3_add(org, v3_scale(dir, t)), p.position);
+    if (fabs(dot3(d, p.right)) > p.rr || fabs(dot3(d, p.upv)) > p.uu) return 0;
+    *out_t = t;
+    if (mode != RTM_MODE_LITERAL) *out_normal = p.normal; /* D2 applies to every Object::Intersect */
+    return 1;
+}
+int rtmo_intersect_object(const rtm_object* o, const double org[3], const double dir[3], int mode, double* out_t,
+                          double out_normal[3]) {
+    if (o->type == RTM_OBJECT_PLANE) {
+        v3 n = v3_from(out_normal);
+        const int hit = intersect_plane(o, v3_from(org), v3_from(dir), mode, out_t, &n);
+        if (hit && mode != RTM_MODE_LITERAL) v3_to(n, out_normal);
+        return hit;
+    }
+    rtm_sphere s;
+    memset(&s, 0, sizeof s);
+    memcpy(s.center, o->position, sizeof s.center);
+    s.radius = o->size;
+    return rtmo_intersect(&s, org, dir, mode, out_t, out_normal);
+}
 
 static inline double draw(rtmo_rng_fn rng, void* ctx, rtmo_counters* c, int is_libc) {
     if (c && !is_libc) c->draws++;
@@ -160,7 +204,11 @@ static v3 path_trace(const pt_env* env, v3 org, v3 dir, rtmo_rng_fn rng, void* r
     for (size_t i = 0; i < env->n; ++i) { /* :62-72 */
         double tmp_dis = 0.0;
         v3 tmp_normal = v3_make(0, 0, 0);
-        int tmp_hit = intersect(&env->spheres[i], org, dir, env->mode, &tmp_dis, &tmp_normal, c);
+        int tmp_hit;
+        if (env->objects && env->objects[i].type == RTM_OBJECT_PLANE)
+            tmp_hit = intersect_plane(&env->objects[i], org, dir, env->mode, &tmp_dis, &tmp_normal);
+        else
+            tmp_hit = intersect(&env->spheres[i], org, dir, env->mode, &tmp_dis, &tmp_normal, c);
         if (tmp_hit && tmp_dis < dis && tmp_dis > 0) { /* :67 strict <, lowest index wins ties */
             dis = tmp_dis;
             normal = tmp_normal;
@@ -215,7 +263,7 @@ static v3 path_trace(const pt_env* env, v3 org, v3 dir, rtmo_rng_fn rng, void* r
 void rtmo_path_trace(const rtm_sphere* spheres, size_t n, int mode, int max_bounces,
                      const double org[3], const double dir[3], rtmo_rng_fn rng, void* rng_ctx,
                      double out_radiance[3], rtmo_counters* counters) {
-    pt_env env = {spheres, n, mode, max_bounces, counters};
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL};
     v3_to(path_trace(&env, v3_from(org), v3_from(dir), rng, rng_ctx, 0, 0), out_radiance);
 }
 
@@ -329,7 +377,7 @@ void rtmo_sample_radiance(const rtm_settings* st, const rtm_sphere* spheres, siz
     v3 cx, cy, cz;
     double fovx, fovy;
     camera_basis(st, &cx, &cy, &cz, &fovx, &fovy);
-    pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters};
+    pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters, NULL};
     v3_to(sample_radiance(st, &env, cx, cy, cz, fovx, fovy, seed_multiplier(opt->seed), x, y, sx,
                           sy, s),
           out_radiance);
@@ -340,7 +388,7 @@ void rtmo_path_trace_stream(const rtm_sphere* spheres, size_t n, int mode, int m
                             const double org[3], const double dir[3], uint64_t seed,
                             uint32_t pixel, uint32_t sample, double out_radiance[3],
                             rtmo_counters* counters) {
-    pt_env env = {spheres, n, mode, max_bounces, counters};
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL};
     rng_stream rs;
     stream_init(&rs, seed_multiplier(seed), pixel, sample);
     v3_to(path_trace(&env, v3_from(org), v3_from(dir), stream_next, &rs, 0, 0), out_radiance);
@@ -385,9 +433,33 @@ int rtmo_max_threads(void) {
 #endif
 }
 
+static int render_core(const rtm_settings* st, const rtm_sphere* spheres, const rtm_object* objects, size_t n,
+                       const rtm_options* opt, double* out, rtmo_counters* counters, int threads,
+                       int structure);
 int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
                 const rtm_options* opt, double* out, rtmo_counters* counters, int threads,
                 int structure) {
+    return render_core(st, spheres, NULL, n, opt, out, counters, threads, structure);
+}
+/* The same for objects of any type: materials and sphere geometry through a parallel rtm_sphere view. */
+int rtmo_render_objects(const rtm_settings* st, const rtm_object* objects, size_t n, const rtm_options* opt,
+                        double* out, rtmo_counters* counters, int threads) {
+    if (!objects && n) return RTM_ERR_INVALID_ARGUMENT;
+    rtm_sphere* view = (rtm_sphere*)calloc(n ? n : 1, sizeof(rtm_sphere));
+    if (!view) return RTM_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(view[i].center, objects[i].position, sizeof view[i].center);
+        memcpy(view[i].color, objects[i].color, sizeof view[i].color);
+        memcpy(view[i].emission, objects[i].emission, sizeof view[i].emission);
+        view[i].radius = objects[i].size;
+    }
+    const int rc = render_core(st, view, objects, n, opt, out, counters, threads, 0);
+    free(view);
+    return rc;
+}
+static int render_core(const rtm_settings* st, const rtm_sphere* spheres, const rtm_object* objects, size_t n,
+                       const rtm_options* opt, double* out, rtmo_counters* counters, int threads,
+                       int structure) {
     if (!st || !opt || !out || (!spheres && n)) return RTM_ERR_INVALID_ARGUMENT;
     if (st->width <= 0 || st->height <= 0 || st->samples <= 0 || st->super_samples <= 0)
         return RTM_ERR_INVALID_ARGUMENT;
@@ -412,7 +484,7 @@ int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
             {
                 rtmo_counters local;
                 memset(&local, 0, sizeof local);
-                pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL};
+                pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, objects};
 #pragma omp for
                 for (int x = 0; x < W; ++x)
                     render_pixel(st, &env, cx, cy, cz, fovx, fovy, seed_mult, x, r0 + yy,
@@ -426,7 +498,7 @@ int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
         {
             rtmo_counters local;
             memset(&local, 0, sizeof local);
-            pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL};
+            pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, objects};
 #pragma omp for schedule(dynamic, 16)
             for (long p = 0; p < (long)rows * W; ++p) {
                 const int yy = (int)(p / W), x = (int)(p % W);
@@ -464,7 +536,7 @@ int rtmo_render_pixels(const rtm_settings* st, const rtm_sphere* spheres, size_t
     {
         rtmo_counters local;
         memset(&local, 0, sizeof local);
-        pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL};
+        pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, NULL};
 #pragma omp for schedule(dynamic, 1)
         for (long p = 0; p < (long)n_pixels; ++p)
             render_pixel(st, &env, cx, cy, cz, fovx, fovy, seed_mult, xy[2 * p], xy[2 * p + 1], out + (size_t)p * 3);

@@ -76,6 +76,13 @@ int rtmo_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
                 const rtm_options* opt, double* out, rtmo_counters* counters, int threads,
                 int structure);
 
+/* Objects of any type (include/rtm.h: rtm_object; planes are a build-defined completion of png::PlaneObject):
+ * the Intersect seam and the render, per-pixel parallel. */
+int rtmo_intersect_object(const rtm_object* o, const double org[3], const double dir[3], int mode, double* out_t,
+                          double out_normal[3]);
+int rtmo_render_objects(const rtm_settings* st, const rtm_object* objects, size_t n, const rtm_options* opt,
+                        double* out, rtmo_counters* counters, int threads);
+
 /* The per-pixel loop of rtmo_render for a list of pixels (xy: n_pixels pairs x, y); out: n_pixels*3. */
 int rtmo_render_pixels(const rtm_settings* st, const rtm_sphere* spheres, size_t n, const rtm_options* opt,
                        const int32_t* xy, size_t n_pixels, double* out, rtmo_counters* counters, int threads);

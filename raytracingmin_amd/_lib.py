@@ -31,6 +31,15 @@ class rtm_sphere(C.Structure):
                 ("emission", C.c_double * 3), ("radius", C.c_float), ("_pad", C.c_float)]
 
 
+class rtm_object(C.Structure):
+    _fields_ = [("type", C.c_int32), ("size", C.c_float), ("position", C.c_double * 3),
+                ("color", C.c_double * 3), ("emission", C.c_double * 3), ("up", C.c_double * 3),
+                ("target", C.c_double * 3), ("width", C.c_double)]
+
+
+OBJECT_SPHERE, OBJECT_PLANE = 1, 2
+
+
 class rtm_settings(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32),
                 ("super_samples", C.c_int32), ("camera", rtm_camera)]
@@ -66,6 +75,7 @@ SIGNATURES = {
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
     "rtm_scene_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_void_p)]),
+    "rtm_scene_create_objects": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, _P(C.c_void_p)]),
     "rtm_scene_destroy": (C.c_int, [C.c_void_p]),
     "rtm_scene_size": (C.c_size_t, [C.c_void_p]),
     "rtm_stream_status": (C.c_int, [C.c_int, C.c_void_p]),
@@ -80,6 +90,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_intersect_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtm_intersect_objects_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_rng_u01": (C.c_double, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rtm_rng_batch": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p]),
@@ -87,6 +99,10 @@ SIGNATURES = {
                                       C.c_size_t, _P(C.c_size_t)]),
     "rtm_scene_parse_json": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, _P(rtm_settings),
                                        C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "rtm_scene_load_json_objects": (C.c_int, [C.c_char_p, C.c_int, _P(rtm_settings), C.c_void_p,
+                                              C.c_size_t, _P(C.c_size_t)]),
+    "rtm_scene_parse_json_objects": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, _P(rtm_settings),
+                                               C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
     "rtm_scene_save_sample_json": (C.c_int, [C.c_char_p]),
     "rtm_scene_make_stress": (C.c_int, [C.c_uint64, C.c_size_t, _P(rtm_settings), C.c_void_p]),
     "rtm_quantise": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -45,6 +45,21 @@ int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on
                      rtm_scene** out_scene) {
     RTM_GUARD(rtm::scene_create(spheres, n_spheres, spheres_on_device, device, out_scene))
 }
+int rtm_scene_create_objects(const rtm_object* objects, size_t n_objects, int device, rtm_scene** out_scene) {
+    RTM_GUARD(rtm::scene_create_objects(objects, n_objects, device, out_scene))
+}
+int rtm_intersect_objects_batch(const rtm_object* objects, const double* org, const double* dir, size_t n, int mode,
+                                int32_t* out_hit, double* out_t, double* out_normal) {
+    RTM_GUARD(rtm::intersect_objects_batch(objects, org, dir, n, mode, out_hit, out_t, out_normal))
+}
+int rtm_scene_load_json_objects(const char* path, int literal_loader, rtm_settings* settings,
+                                rtm_object* objects, size_t capacity, size_t* n_objects) {
+    RTM_GUARD(rtm::scene_load_json_objects(path, literal_loader, settings, objects, capacity, n_objects))
+}
+int rtm_scene_parse_json_objects(const char* text, size_t len, int literal_loader, rtm_settings* settings,
+                                 rtm_object* objects, size_t capacity, size_t* n_objects) {
+    RTM_GUARD(rtm::scene_parse_json_objects(text, len, literal_loader, settings, objects, capacity, n_objects))
+}
 int rtm_scene_destroy(rtm_scene* scene) { RTM_GUARD(rtm::scene_destroy(scene)) }
 size_t rtm_scene_size(const rtm_scene* scene) { return rtm::scene_size(scene); }
 int rtm_stream_status(int device, void* stream) { RTM_GUARD(rtm::stream_status(device, stream)) }

@@ -21,6 +21,9 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
                      int32_t* out_id, double* out_t);
 const char* variant_name(int v);
 int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_scene** out);
+int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene** out);
+int intersect_objects_batch(const rtm_object* objs, const double* org, const double* dir, size_t n, int mode,
+                            int32_t* out_hit, double* out_t, double* out_normal);
 int scene_destroy(rtm_scene* sc);
 size_t scene_size(const rtm_scene* sc);
 int stream_status(int device, void* stream);
@@ -47,6 +50,10 @@ int math_probe(int op, const double* a, const double* b, size_t n, double* out);
 // host side (rtm_scene.cpp, rtm_image.cpp)
 int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* st,
                      rtm_sphere* spheres, size_t capacity, size_t* n_spheres);
+int scene_parse_json_objects(const char* text, size_t len, int literal_loader, rtm_settings* st,
+                             rtm_object* objects, size_t capacity, size_t* n_objects);
+int scene_load_json_objects(const char* path, int literal_loader, rtm_settings* st, rtm_object* objects,
+                            size_t capacity, size_t* n_objects);
 int scene_load_json(const char* path, int literal_loader, rtm_settings* st, rtm_sphere* spheres,
                     size_t capacity, size_t* n_spheres);
 int scene_save_sample_json(const char* path);

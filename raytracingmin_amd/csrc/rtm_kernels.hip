@@ -925,19 +925,22 @@ __global__ __launch_bounds__(64) void intersect_pairs_kernel(const double4* __re
                                                              size_t n, int mode,
                                                              int32_t* __restrict__ out_hit,
                                                              double* __restrict__ out_t,
-                                                             double* __restrict__ out_normal) {
+                                                             double* __restrict__ out_normal,
+                                                             const double* __restrict__ plane = nullptr) {
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const D3 o = d3(org[i * 3], org[i * 3 + 1], org[i * 3 + 2]);
     const D3 d = d3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
     const double4 g = geom[i];
     double t;
-    const bool hit = sphere_test<MathRef>(g, o, d, t);
+    const bool is_plane = plane != nullptr && g.w < 0.0;
+    const bool hit = is_plane ? plane_test(plane + i * 16, o, d, t) : sphere_test<MathRef>(g, o, d, t);
     out_hit[i] = hit ? 1 : 0;
     if (hit) {
         out_t[i] = t;
         if (mode != RTM_MODE_LITERAL) {  // D2: literal mode never delivers the normal
-            const D3 nrm = normalize((o + d * t) - d3(g.x, g.y, g.z));  // src/SettingData.cpp:214-215
+            const D3 nrm = is_plane ? d3(plane[i * 16 + 3], plane[i * 16 + 4], plane[i * 16 + 5])
+                                    : normalize((o + d * t) - d3(g.x, g.y, g.z));  // src/SettingData.cpp:214-215
             out_normal[i * 3] = nrm.x;
             out_normal[i * 3 + 1] = nrm.y;
             out_normal[i * 3 + 2] = nrm.z;
@@ -1234,7 +1237,8 @@ struct EventPair {
 struct rtm_scene {
     int device = 0;
     size_t n = 0;
-    rtm::DevMem geom, mat, aux;
+    rtm::DevMem geom, mat, aux, plane;  // plane: 16 doubles per object, only for scenes that hold planes
+    bool has_planes = false;
     uint64_t content_hash = 0;  // cache entries only
 };
 
@@ -1258,8 +1262,10 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
     RTM_HIP_CHECK(hipGetLastError());
     return RTM_OK;
 }
-static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n) {
+static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n,
+                            const double* plane = nullptr) {
     SceneView v{(const double4*)geom, mat, (int)n};
+    v.plane = plane;
     if (aux) {
         const size_t n_pad = (n + 7) & ~(size_t)7;
         v.bounds = aux;
@@ -1317,6 +1323,97 @@ int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_
     *out = sc.release();
     return RTM_OK;
 }
+// png::PlaneObject's constructor (src/SettingData.cpp:235-242) on the host, in the reference's operation order;
+// `upv` and the two squared half-extents are this build's completion (include/rtm.h).
+static void plane_row(const rtm_object& o, double row[16]) {
+    using namespace host;
+    const H3 pos = {o.position[0], o.position[1], o.position[2]};
+    const H3 nrm = normalize(sub(H3{o.target[0], o.target[1], o.target[2]}, pos));  // :240
+    const H3 rn = normalize(cross(nrm, H3{o.up[0], o.up[1], o.up[2]}));             // :241 Normalize(Cross(..))
+    const H3 right = {rn.x * 0.5 * o.width, rn.y * 0.5 * o.width, rn.z * 0.5 * o.width};  // (v * 0.5) * width
+    const H3 upv = cross(right, nrm);
+    const double v[16] = {pos.x, pos.y, pos.z, nrm.x, nrm.y, nrm.z, right.x, right.y, right.z, upv.x, upv.y, upv.z,
+                          right.x * right.x + right.y * right.y + right.z * right.z,
+                          upv.x * upv.x + upv.y * upv.y + upv.z * upv.z, 0.0, 0.0};
+    std::memcpy(row, v, sizeof v);
+}
+
+int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene** out) {
+    if (!out || (!objs && n) || n > 0x7FFFFFFFull) {
+        set_last_error("null argument or scene too large");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    *out = nullptr;
+    std::vector<rtm_sphere> view(n ? n : 1);
+    std::vector<double> rows(n * 16, 0.0);
+    bool any_plane = false;
+    for (size_t i = 0; i < n; ++i) {
+        if (objs[i].type != RTM_OBJECT_SPHERE && objs[i].type != RTM_OBJECT_PLANE) {
+            set_last_error("unknown object type (1 = sphere, 2 = plane)");
+            return RTM_ERR_INVALID_SCENE;
+        }
+        std::memset(&view[i], 0, sizeof view[i]);
+        for (int k = 0; k < 3; ++k) {
+            view[i].center[k] = objs[i].position[k];
+            view[i].color[k] = objs[i].color[k];
+            view[i].emission[k] = objs[i].emission[k];
+        }
+        view[i].radius = objs[i].size;
+        if (objs[i].type == RTM_OBJECT_PLANE) {
+            any_plane = true;
+            plane_row(objs[i], &rows[i * 16]);
+        }
+    }
+    std::unique_ptr<rtm_scene> sc(new rtm_scene);
+    int rc = scene_build_host(*sc, view.data(), n, device);
+    if (rc != RTM_OK) return rc;
+    if (any_plane) {
+        // a plane's geometry row is (position, -1): the negative "r*r" marks it for the per-object loop
+        std::vector<double> hg(n * 4);
+        RTM_HIP_CHECK(hipMemcpy(hg.data(), sc->geom.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i)
+            if (objs[i].type == RTM_OBJECT_PLANE) hg[i * 4 + 3] = -1.0;
+        RTM_HIP_CHECK(hipMemcpy(sc->geom.p, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice));
+        if ((rc = sc->plane.alloc(rows.size() * sizeof(double))) != RTM_OK) return rc;
+        RTM_HIP_CHECK(hipMemcpy(sc->plane.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+        sc->has_planes = true;
+    }
+    *out = sc.release();
+    return RTM_OK;
+}
+
+int intersect_objects_batch(const rtm_object* objs, const double* org, const double* dir, size_t n, int mode,
+                            int32_t* out_hit, double* out_t, double* out_normal) {
+    if (!objs || !org || !dir || !out_hit || !out_t || !out_normal) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return RTM_OK;
+    int device = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    rtm_scene* raw = nullptr;
+    int rc = scene_create_objects(objs, n, device, &raw);
+    if (rc != RTM_OK) return rc;
+    std::unique_ptr<rtm_scene> ds(raw);
+    DevMem d_org, d_dir, d_t, d_n, d_hit;
+    const size_t vb = n * 3 * sizeof(double);
+    if ((rc = d_org.alloc(vb)) != RTM_OK || (rc = d_dir.alloc(vb)) != RTM_OK || (rc = d_n.alloc(vb)) != RTM_OK ||
+        (rc = d_t.alloc(n * sizeof(double))) != RTM_OK || (rc = d_hit.alloc(n * sizeof(int32_t))) != RTM_OK)
+        return rc;
+    RTM_HIP_CHECK(hipMemcpy(d_org.p, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir.p, dir, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_n.p, out_normal, vb, hipMemcpyHostToDevice));  // untouched where no hit
+    RTM_HIP_CHECK(hipMemcpy(d_t.p, out_t, n * sizeof(double), hipMemcpyHostToDevice));
+    intersect_pairs_kernel<<<(unsigned)((n + 63) / 64), 64>>>((const double4*)ds->geom.p, d_org.as<double>(), d_dir.as<double>(),
+                                                              n, mode, d_hit.as<int32_t>(), d_t.as<double>(), d_n.as<double>(),
+                                                              ds->has_planes ? ds->plane.as<double>() : nullptr);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipMemcpy(out_hit, d_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_t, d_t.p, n * sizeof(double), hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_normal, d_n.p, vb, hipMemcpyDeviceToHost));
+    return RTM_OK;
+}
+
 int scene_destroy(rtm_scene* sc) {
     if (!sc) return RTM_OK;
     // renders that use the scene may still be queued: wait for the device before its memory goes
@@ -2050,6 +2147,13 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                   n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
     else if (variant == kVariantSplit)
         variant = kVariantFastLds;
+    if (view.plane != nullptr) {  // png::PlaneObject in the scene: the per-object loop with the compiler's math
+        if (opt->variant != kVariantAuto && opt->variant != kVariantRef) {
+            set_last_error("scenes that hold planes are rendered by variant 0 (auto) or 1 (per-object loop)");
+            return RTM_ERR_UNSUPPORTED;
+        }
+        variant = kVariantRef;
+    }
     if (variant == kVariantPrimaryReuse &&
         !(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && P.max_bounces >= 0 && P.max_bounces <= 8)) {
         set_last_error("variant 15 (primary-hit reuse) serves scenes of 1..24 spheres with 0 <= max_bounces <= 8");
@@ -2165,7 +2269,8 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
         return RTM_ERR_INVALID_ARGUMENT;
     }
     std::shared_lock<std::shared_mutex> gate(g_gate);
-    return render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n),
+    return render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
+                                      scene->has_planes ? scene->plane.as<double>() : nullptr),
                        scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
 }
 

@@ -406,7 +406,26 @@ struct SceneView {
     // RTM_MODE_HOST_TRIG: 4 bits per possible r1 (2^23 of them): the differences, in units of the last
     // place, between the host libm's sin/cos and the device's (rtm_kernels.hip, ensure_trig_fix)
     const uint32_t* __restrict__ trig_fix = nullptr;
+    // scenes with png::PlaneObject entries (include/rtm.h: rtm_object): 16 doubles per object — position, normal,
+    // right, upv, right.right, upv.upv, 0, 0 — valid where geom[i].w < 0 (a sphere's r*r is never negative); null
+    // for all-sphere scenes.  Served by the per-object loop only (variant 1).
+    const double* __restrict__ plane = nullptr;
 };
+
+// png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line
+// (src/SettingData.cpp:244), the sphere's near threshold, then the square's extent.
+__device__ __forceinline__ bool plane_test(const double* __restrict__ pl, const D3 org, const D3 dir, double& t) {
+    const D3 pos = d3(pl[0], pl[1], pl[2]), nrm = d3(pl[3], pl[4], pl[5]);
+    const double dn = dot(nrm, dir);
+    if (fabs(dn) < (double)FLT_EPSILON) return false;
+    const double tt = dot(nrm, pos - org) / dn;
+    if (!(tt > 0.001)) return false;
+    const D3 d = (org + dir * tt) - pos;
+    const D3 right = d3(pl[6], pl[7], pl[8]), upv = d3(pl[9], pl[10], pl[11]);
+    if (fabs(dot(d, right)) > pl[12] || fabs(dot(d, upv)) > pl[13]) return false;
+    t = tt;
+    return true;
+}
 
 // sin(r1), cos(r1) as the HOST's libm returns them (src/Renderer.cpp:93-94 call std::sin / std::cos):
 // r1 = 2*pi*u takes one of 2^23 values, so the device's results are compared once with the host's over
@@ -654,7 +673,12 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
         for (int i = 0; i < n; ++i) {
             const double4 g = sc.geom_uniform(i);
             double t;
-            if (sphere_test<M>(g, org, dir, t) && t < dis && t > 0) {
+            bool hit;
+            if (sc.v.plane != nullptr && g.w < 0.0)  // wave-uniform: object i is a plane
+                hit = plane_test(sc.v.plane + (size_t)i * 16, org, dir, t);
+            else
+                hit = sphere_test<M>(g, org, dir, t);
+            if (hit && t < dis && t > 0) {
                 dis = t;
                 hit_object = i;
             }
@@ -740,11 +764,19 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     // D2: in literal mode the caller's normal stays (0,0,0); repaired: src/SettingData.cpp:214-215
     D3 normal = d3(0, 0, 0);
     if (mode != RTM_MODE_LITERAL) {
-        const D3 dv = hit_point - sc.center(id);
-        if constexpr (Scene::kHasNormTable && std::is_same<MI, MathSpec>::value)
-            normal = m.normalize_on_sphere(dv, sc.norm_m(id), sc.norm_rinv(id), sc.norm_r2f(id));
-        else
-            normal = normalize_i(m, dv);
+        if (sc.v.plane != nullptr) {  // wave-uniform: the scene holds planes (per-object kernel, MathRefI)
+            const bool is_plane = sc.v.geom[id].w < 0.0;
+            const double* pl = sc.v.plane + (size_t)id * 16;
+            const D3 nsphere = normalize_i(m, hit_point - sc.center(id));
+            normal = is_plane ? d3(pl[3], pl[4], pl[5]) : nsphere;  // PlaneObject: out_normal = m_normal
+            if constexpr (std::is_same<MI, MathSpec>::value) m.bad = m.bad | is_plane;  // its shortcuts assume spheres
+        } else {
+            const D3 dv = hit_point - sc.center(id);
+            if constexpr (Scene::kHasNormTable && std::is_same<MI, MathSpec>::value)
+                normal = m.normalize_on_sphere(dv, sc.norm_m(id), sc.norm_rinv(id), sc.norm_r2f(id));
+            else
+                normal = normalize_i(m, dv);
+        }
     }
     // :82-83  w = Dot(n, d) < 0 ? n : n * -1.0  (multiplying by -1.0 flips the sign bit, exactly)
     const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));

@@ -5,7 +5,8 @@
 // Loader rules so the shipped ExampleScene/*.json run unchanged:
 //   missing "00 objectType" => 1 (sphere); objects without "00 position" are skipped (the "{}" in
 //   cornellBoxSetting.json:47); "00 sample" is accepted for "00 samples"; missing samples /
-//   superSamples default to 10 / 1; unknown keys are ignored like from_json does; objectType != 1
+//   superSamples default to 10 / 1; unknown keys are ignored like from_json does; objectType 2 is the
+//   build-defined plane (rtm.h: rtm_object; keys "03 up", "04 target", "01 size" = width); any other objectType
 //   is an error (HEAD would push a nullptr and crash at src/Renderer.cpp:66).
 #include <cerrno>
 #include <cmath>
@@ -271,12 +272,11 @@ void read_vec3(const JsonValue& v, const char* what, double out[3]) {
 
 }  // namespace
 
-int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* st,
-                     rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
-    if (!text || !st || !n_spheres || (!spheres && capacity)) {
-        set_last_error("null argument");
-        return RTM_ERR_INVALID_ARGUMENT;
-    }
+// The parser proper: every object becomes an rtm_object (type 1 = sphere; type 2 = plane, a build-defined
+// extension of the schema — the reference's loader builds only type 1 and pushes a null Object* for anything
+// else, src/SettingData.cpp:161-179).
+static int parse_json_objects(const char* text, size_t len, int literal_loader, rtm_settings* st,
+                              std::vector<rtm_object>& objs) {
     try {
         const JsonValue root = JsonParser(text, len).parse();
         if (root.kind != JsonValue::Object) throw JsonError("type error: document must be an object");
@@ -284,7 +284,6 @@ int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_setti
         st->samples = 10;       // HEAD leaves these indeterminate when the key is absent
         st->super_samples = 1;  // (src/SettingData.h:47-51); build defaults, SURVEY Appendix C
         bool have_w = false, have_h = false;
-        std::vector<rtm_sphere> objs;
         // reference: for (auto& it : json.items()) key-by-key (src/SettingData.cpp:130-184)
         for (const auto& kv : root.obj) {
             const std::string& key = kv.first;
@@ -324,28 +323,38 @@ int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_setti
                         if (!pos) continue;  // e.g. the "{}" entry of cornellBoxSetting.json
                         int object_type = 1;
                         if (const JsonValue* t = o->find("00 objectType")) object_type = t->as_int("00 objectType");
-                        if (object_type != 1) {
+                        if (object_type != RTM_OBJECT_SPHERE && object_type != RTM_OBJECT_PLANE) {
                             set_last_error("objectType " + std::to_string(object_type) +
-                                           " is not supported (only 1 = sphere; the reference would "
+                                           " is not supported (1 = sphere, 2 = plane; the reference would "
                                            "dereference a null Object*)");
                             return RTM_ERR_INVALID_SCENE;
                         }
-                        rtm_sphere s;
+                        rtm_object s;
                         std::memset(&s, 0, sizeof s);
+                        s.type = object_type;
                         double p[3];
                         read_vec3(*pos, "00 position", p);
                         if (literal_loader) {  // src/SettingData.cpp:165-167: posi.x = [0]; = [1]; = [2]
-                            s.center[0] = p[2];
-                            s.center[1] = 0.0;
-                            s.center[2] = 0.0;
+                            s.position[0] = p[2];
+                            s.position[1] = 0.0;
+                            s.position[2] = 0.0;
                         } else {
-                            s.center[0] = p[0];
-                            s.center[1] = p[1];
-                            s.center[2] = p[2];
+                            s.position[0] = p[0];
+                            s.position[1] = p[1];
+                            s.position[2] = p[2];
                         }
                         const JsonValue* size = o->find("01 size");
                         if (!size) throw JsonError("type error: object without \"01 size\"");
-                        s.radius = (float)size->as_double("01 size");  // double size -> const float size
+                        if (object_type == RTM_OBJECT_SPHERE) {
+                            s.size = (float)size->as_double("01 size");  // double size -> const float size
+                        } else {  // PlaneObject(position, up, target, const double width, mat)
+                            s.width = size->as_double("01 size");
+                            const JsonValue* up = o->find("03 up");
+                            const JsonValue* tg = o->find("04 target");
+                            if (!up || !tg) throw JsonError("type error: a plane needs \"03 up\" and \"04 target\"");
+                            read_vec3(*up, "03 up", s.up);
+                            read_vec3(*tg, "04 target", s.target);
+                        }
                         const JsonValue* mat = o->find("02 material");
                         if (!mat || mat->kind != JsonValue::Object)
                             throw JsonError("type error: object without \"02 material\"");
@@ -363,14 +372,6 @@ int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_setti
             set_last_error("\"00 width\" and \"00 height\" are required");
             return RTM_ERR_INVALID_SCENE;
         }
-        *n_spheres = objs.size();
-        if (spheres) {
-            if (objs.size() > capacity) {
-                set_last_error("sphere buffer too small");
-                return RTM_ERR_CAPACITY;
-            }
-            if (!objs.empty()) std::memcpy(spheres, objs.data(), objs.size() * sizeof(rtm_sphere));
-        }
         return RTM_OK;
     } catch (const JsonError& e) {
         set_last_error(e.what());
@@ -378,8 +379,61 @@ int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_setti
     }
 }
 
-int scene_load_json(const char* path, int literal_loader, rtm_settings* st, rtm_sphere* spheres,
-                    size_t capacity, size_t* n_spheres) {
+int scene_parse_json_objects(const char* text, size_t len, int literal_loader, rtm_settings* st,
+                             rtm_object* objects, size_t capacity, size_t* n_objects) {
+    if (!text || !st || !n_objects || (!objects && capacity)) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<rtm_object> objs;
+    const int rc = parse_json_objects(text, len, literal_loader, st, objs);
+    if (rc != RTM_OK) return rc;
+    *n_objects = objs.size();
+    if (objects) {
+        if (objs.size() > capacity) {
+            set_last_error("object buffer too small");
+            return RTM_ERR_CAPACITY;
+        }
+        if (!objs.empty()) std::memcpy(objects, objs.data(), objs.size() * sizeof(rtm_object));
+    }
+    return RTM_OK;
+}
+
+int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* st,
+                     rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {
+    if (!text || !st || !n_spheres || (!spheres && capacity)) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<rtm_object> objs;
+    const int rc = parse_json_objects(text, len, literal_loader, st, objs);
+    if (rc != RTM_OK) return rc;
+    for (const rtm_object& o : objs)
+        if (o.type != RTM_OBJECT_SPHERE) {
+            set_last_error("the scene holds a plane (objectType 2): load it with rtm_scene_load_json_objects");
+            return RTM_ERR_INVALID_SCENE;
+        }
+    *n_spheres = objs.size();
+    if (spheres) {
+        if (objs.size() > capacity) {
+            set_last_error("sphere buffer too small");
+            return RTM_ERR_CAPACITY;
+        }
+        for (size_t i = 0; i < objs.size(); ++i) {
+            rtm_sphere& s = spheres[i];
+            std::memset(&s, 0, sizeof s);
+            for (int k = 0; k < 3; ++k) {
+                s.center[k] = objs[i].position[k];
+                s.color[k] = objs[i].color[k];
+                s.emission[k] = objs[i].emission[k];
+            }
+            s.radius = objs[i].size;
+        }
+    }
+    return RTM_OK;
+}
+
+static int read_file(const char* path, std::string& text) {
     if (!path) {
         set_last_error("null path");
         return RTM_ERR_INVALID_ARGUMENT;
@@ -391,7 +445,23 @@ int scene_load_json(const char* path, int literal_loader, rtm_settings* st, rtm_
     }
     std::stringstream ss;
     ss << f.rdbuf();
-    const std::string text = ss.str();
+    text = ss.str();
+    return RTM_OK;
+}
+
+int scene_load_json_objects(const char* path, int literal_loader, rtm_settings* st, rtm_object* objects,
+                            size_t capacity, size_t* n_objects) {
+    std::string text;
+    const int rc = read_file(path, text);
+    if (rc != RTM_OK) return rc;
+    return scene_parse_json_objects(text.data(), text.size(), literal_loader, st, objects, capacity, n_objects);
+}
+
+int scene_load_json(const char* path, int literal_loader, rtm_settings* st, rtm_sphere* spheres,
+                    size_t capacity, size_t* n_spheres) {
+    std::string text;
+    const int rc = read_file(path, text);
+    if (rc != RTM_OK) return rc;
     return scene_parse_json(text.data(), text.size(), literal_loader, st, spheres, capacity, n_spheres);
 }
 

@@ -42,9 +42,14 @@ class Renderer:
         key = (id(self.data.object), len(self.data.object))
         if self._scene is None or key != self._scene_key:
             self.invalidate()
-            arr, n = self.data.spheres_c()
             h = C.c_void_p()
-            _lib.check(_lib.lib().rtm_scene_create(arr, n, 0, self.device, C.byref(h)), "rtm_scene_create")
+            if self.data.has_planes():  # png::PlaneObject entries: the any-type object list
+                arr, n = self.data.objects_c()
+                _lib.check(_lib.lib().rtm_scene_create_objects(arr, n, self.device, C.byref(h)),
+                           "rtm_scene_create_objects")
+            else:
+                arr, n = self.data.spheres_c()
+                _lib.check(_lib.lib().rtm_scene_create(arr, n, 0, self.device, C.byref(h)), "rtm_scene_create")
             self._scene, self._scene_key = h, key
         return self._scene
 
@@ -116,6 +121,9 @@ class Renderer:
             out["f32"] = np.zeros((rows, W, 3), dtype=np.float32)
         if "u8" in want:
             out["u8"] = np.zeros((rows, W, 3), dtype=np.uint8)
+        if self.data.has_planes():  # rtm_render takes sphere arrays; planes go through the scene handle
+            dev_out, self.stats = self.render_rows_device(row_begin, row_end, want=want, band=band)
+            return {k: v.cpu().numpy() for k, v in dev_out.items()}, self.stats
         st, arr, n = self.data.to_c()
         s = rtm_stats()
         ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
@@ -157,6 +165,20 @@ def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_b
                                                draws.ctypes.data, casts.ctypes.data),
                "rtm_path_trace_batch")
     return out, draws, casts
+
+
+def intersect_objects_batch(objects_c, org, direction, mode="repaired", t_init=-1.0, n_init=7.0):
+    """Object::Intersect for rtm_object entries (spheres and planes), pair i = (ray i, object i)."""
+    org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n = org.shape[0]
+    hit = np.zeros(n, dtype=np.int32)
+    t = np.full(n, t_init, dtype=np.float64)
+    nrm = np.full((n, 3), n_init, dtype=np.float64)
+    _lib.check(_lib.lib().rtm_intersect_objects_batch(objects_c, org.ctypes.data, direction.ctypes.data, n,
+                                                      _lib.MODES[mode], hit.ctypes.data, t.ctypes.data,
+                                                      nrm.ctypes.data), "rtm_intersect_objects_batch")
+    return hit, t, nrm
 
 
 def intersect_batch(spheres_c, org, direction, mode="repaired", t_init=-1.0, n_init=7.0):

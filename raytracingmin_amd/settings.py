@@ -10,7 +10,7 @@ from dataclasses import dataclass, field
 from typing import List
 
 from . import _lib
-from ._lib import rtm_settings, rtm_sphere
+from ._lib import rtm_object, rtm_settings, rtm_sphere
 
 
 @dataclass
@@ -33,6 +33,18 @@ class Material:  # src/SettingData.h:8-17
 class SphereObject:  # src/SettingData.h:25-32; m_size is a float in the reference
     m_position: vec3 = field(default_factory=vec3)
     m_size: float = 1.0
+    m_material: Material = field(default_factory=Material)
+
+
+@dataclass
+class PlaneObject:
+    """png::PlaneObject(position, up, target, width, mat) — src/SettingData.h:33-42, src/SettingData.cpp:235-242.
+    The reference leaves its Intersect unfinished; this build completes it as the finite square the constructor
+    describes (include/rtm.h: rtm_object) — a build-defined semantics."""
+    m_position: vec3 = field(default_factory=vec3)
+    m_up: vec3 = field(default_factory=lambda: vec3(0, 1, 0))
+    target: vec3 = field(default_factory=lambda: vec3(0, 0, 1))
+    width: float = 1.0
     m_material: Material = field(default_factory=Material)
 
 
@@ -72,7 +84,35 @@ class SettingData:  # src/SettingData.h:47-51
         st.camera.fov = float(self.camera.fov)
         return st
 
+    def has_planes(self):
+        return any(isinstance(o, PlaneObject) for o in self.object)
+
+    def objects_c(self):
+        """The object vector as rtm_object[] (spheres and planes in the reference's vector order)."""
+        n = len(self.object)
+        arr = (rtm_object * max(n, 1))()
+        for i, o in enumerate(self.object):
+            plane = isinstance(o, PlaneObject)
+            arr[i].type = _lib.OBJECT_PLANE if plane else _lib.OBJECT_SPHERE
+            for k, v in enumerate(o.m_position):
+                arr[i].position[k] = float(v)
+            for k, v in enumerate(o.m_material.color):
+                arr[i].color[k] = float(v)
+            for k, v in enumerate(o.m_material.emission):
+                arr[i].emission[k] = float(v)
+            if plane:
+                for k, v in enumerate(o.m_up):
+                    arr[i].up[k] = float(v)
+                for k, v in enumerate(o.target):
+                    arr[i].target[k] = float(v)
+                arr[i].width = float(o.width)
+            else:
+                arr[i].size = float(o.m_size)
+        return arr, n
+
     def spheres_c(self):
+        if self.has_planes():
+            raise ValueError("the scene holds planes: use objects_c()")
         n = len(self.object)
         arr = (rtm_sphere * max(n, 1))()
         for i, o in enumerate(self.object):
@@ -95,6 +135,18 @@ class SettingData:  # src/SettingData.h:47-51
         return SettingData(int(st.width), int(st.height), int(st.samples), int(st.super_samples),
                            cam, objs)
 
+    @staticmethod
+    def from_c_objects(st, arr, n):
+        data = SettingData.from_c(st, (rtm_sphere * 1)(), 0)
+        for i in range(n):
+            mat = Material(vec3(*arr[i].color), vec3(*arr[i].emission))
+            if arr[i].type == _lib.OBJECT_PLANE:
+                data.object.append(PlaneObject(vec3(*arr[i].position), vec3(*arr[i].up), vec3(*arr[i].target),
+                                               float(arr[i].width), mat))
+            else:
+                data.object.append(SphereObject(vec3(*arr[i].position), float(arr[i].size), mat))
+        return data
+
 
 class LoadData:
     """png::LoadData (src/SettingData.cpp:6-12): LoadData(path).data is the SettingData.
@@ -107,12 +159,12 @@ class LoadData:
         st = rtm_settings()
         n = C.c_size_t(0)
         path = os.fsencode(jsonName)
-        _lib.check(L.rtm_scene_load_json(path, int(literal_loader), C.byref(st), None, 0,
-                                         C.byref(n)), f"LoadData({jsonName})")
-        arr = (rtm_sphere * max(n.value, 1))()
-        _lib.check(L.rtm_scene_load_json(path, int(literal_loader), C.byref(st), arr, n.value,
-                                         C.byref(n)), f"LoadData({jsonName})")
-        self.data = SettingData.from_c(st, arr, n.value)
+        _lib.check(L.rtm_scene_load_json_objects(path, int(literal_loader), C.byref(st), None, 0,
+                                                 C.byref(n)), f"LoadData({jsonName})")
+        arr = (rtm_object * max(n.value, 1))()
+        _lib.check(L.rtm_scene_load_json_objects(path, int(literal_loader), C.byref(st), arr, n.value,
+                                                 C.byref(n)), f"LoadData({jsonName})")
+        self.data = SettingData.from_c_objects(st, arr, n.value)
 
     @staticmethod
     def SaveSampleJson(fileName):  # src/SettingData.cpp:14-24,100-103

@@ -29,6 +29,12 @@ class Sphere(C.Structure):
                 ("emission", C.c_double * 3), ("radius", C.c_float), ("_pad", C.c_float)]
 
 
+class Object(C.Structure):  # include/rtm.h: rtm_object
+    _fields_ = [("type", C.c_int32), ("size", C.c_float), ("position", C.c_double * 3),
+                ("color", C.c_double * 3), ("emission", C.c_double * 3), ("up", C.c_double * 3),
+                ("target", C.c_double * 3), ("width", C.c_double)]
+
+
 class Settings(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32),
                 ("super_samples", C.c_int32), ("camera", Camera)]
@@ -83,6 +89,11 @@ def lib():
         L.rtmo_render_pixels.restype = C.c_int
         L.rtmo_render_pixels.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t, C.POINTER(Options),
                                          C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Counters), C.c_int]
+        L.rtmo_render_objects.restype = C.c_int
+        L.rtmo_render_objects.argtypes = [C.POINTER(Settings), C.POINTER(Object), C.c_size_t, C.POINTER(Options),
+                                          C.c_void_p, C.POINTER(Counters), C.c_int]
+        L.rtmo_intersect_object.restype = C.c_int
+        L.rtmo_intersect_object.argtypes = [C.POINTER(Object), _D3, _D3, C.c_int, C.POINTER(C.c_double), _D3]
         L.rtmo_sample_radiance.restype = None
         L.rtmo_sample_radiance.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t,
                                            C.POINTER(Options), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -185,6 +196,24 @@ def render_pixels(st, spheres, n, opt, xy, threads=0):
     if rc != 0:
         raise RuntimeError(f"rtmo_render_pixels failed: {rc}")
     return out, cnt.as_dict()
+
+
+def render_objects(st, objects, n, opt, threads=0):
+    """rtmo_render_objects: a scene of rtm_object entries (spheres and planes)."""
+    rows = opt.row_end - opt.row_begin
+    out = np.zeros((rows, st.width, 3), dtype=np.float64)
+    cnt = Counters()
+    rc = lib().rtmo_render_objects(C.byref(st), objects, n, C.byref(opt), out.ctypes.data, C.byref(cnt), threads)
+    if rc != 0:
+        raise RuntimeError(f"rtmo_render_objects failed: {rc}")
+    return out, cnt.as_dict()
+
+
+def intersect_object(obj, org, direction, mode, t_init=-1.0, n_init=7.0):
+    t = C.c_double(t_init)
+    nrm = _D3(n_init, n_init, n_init)
+    hit = lib().rtmo_intersect_object(C.byref(obj), _D3(*org), _D3(*direction), mode, C.byref(t), nrm)
+    return hit, t.value, [nrm[0], nrm[1], nrm[2]]
 
 
 def path_trace(spheres, n, mode, max_bounces, org, direction, rng):

@@ -46,10 +46,11 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.rtm_settings) == 96
     assert C.sizeof(_lib.rtm_options) == 40
     assert C.sizeof(_lib.rtm_stats) == 48
+    assert C.sizeof(_lib.rtm_object) == 136
     # the oracle's view of the same PODs
     import _oracle
     assert C.sizeof(_oracle.Sphere) == 80 and C.sizeof(_oracle.Settings) == 96
-    assert C.sizeof(_oracle.Options) == 40
+    assert C.sizeof(_oracle.Options) == 40 and C.sizeof(_oracle.Object) == 136
 
 
 def test_strerror_and_variants():

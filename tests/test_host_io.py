@@ -70,10 +70,26 @@ def test_loader_edge_cases():
     assert arr[0].radius == np.float32(0.1)
     rc, st, arr, n = _parse(json.dumps(doc), literal=1)
     assert list(arr[0].center) == [3, 0, 0]  # D1
+    doc["02 scene"]["00 object"][0]["00 objectType"] = 3
+    rc, *_ = _parse(json.dumps(doc))
+    assert rc == -2 and b"objectType" in _lib.lib().rtm_last_error_detail()  # the reference would push a null Object*
+    # objectType 2 = png::PlaneObject, a build-defined extension of the schema (include/rtm.h: rtm_object)
     doc["02 scene"]["00 object"][0]["00 objectType"] = 2
     rc, *_ = _parse(json.dumps(doc))
-    assert rc == -2 and b"objectType" in _lib.lib().rtm_last_error_detail()
+    assert rc == -4 and b"plane" in _lib.lib().rtm_last_error_detail()      # needs "03 up" and "04 target"
+    doc["02 scene"]["00 object"][0].update({"03 up": [0, 1, 0], "04 target": [1, 2, 4], "01 size": 2.5})
+    rc, *_ = _parse(json.dumps(doc))
+    assert rc == -2 and b"rtm_scene_load_json_objects" in _lib.lib().rtm_last_error_detail()  # sphere-only loader
+    L = _lib.lib()
+    b = json.dumps(doc).encode()
+    st2, n2 = _lib.rtm_settings(), C.c_size_t()
+    objs = (_lib.rtm_object * 4)()
+    assert L.rtm_scene_parse_json_objects(b, len(b), 0, C.byref(st2), objs, 4, C.byref(n2)) == 0 and n2.value == 2
+    assert (objs[0].type, objs[0].width, list(objs[0].up), list(objs[0].target)) == (2, 2.5, [0, 1, 0], [1, 2, 4])
+    assert (objs[1].type, objs[1].size, list(objs[1].position)) == (1, np.float32(0.1), [1, 2, 3])
     doc["02 scene"]["00 object"][0]["00 objectType"] = 1
+    for k in ("03 up", "04 target"):
+        del doc["02 scene"]["00 object"][0][k]
     doc["02 scene"]["00 object"][0]["01 size"] = "big"
     rc, *_ = _parse(json.dumps(doc))
     assert rc == -4  # nlohmann would throw type_error
@@ -151,3 +167,36 @@ def test_jpeg_is_decodable_baseline(tmp_path):
         err = np.abs(np.array(im.convert("RGB")).astype(int) - img)
         assert err.mean() < 4 and err.max() < 40
     assert _lib.lib().rtm_write_jpg(b"/nonexistent/dir/a.jpg", 70, 50, 3, img.ctypes.data, 60) == 0
+
+
+def test_plane_objects_in_the_oracle(oracle):
+    """png::PlaneObject as this build completes it (include/rtm.h): the oracle's Intersect for a unit square
+    facing the ray — inside / outside the extent, grazing, behind, and the literal mode's lost normal."""
+    o = oracle.Object()
+    o.type = 2
+    for k, v in enumerate((0.0, 0.0, 5.0)):
+        o.position[k] = v
+    for k, v in enumerate((0.0, 1.0, 0.0)):
+        o.up[k] = v
+    for k, v in enumerate((0.0, 0.0, 4.0)):   # normal (0, 0, -1): towards the camera
+        o.target[k] = v
+    o.width = 2.0
+    hit, t, n = oracle.intersect_object(o, (0.2, -0.3, 0), (0, 0, 1), 1)
+    assert hit == 1 and t == 5.0 and n == [0.0, 0.0, -1.0]
+    hit, t, n = oracle.intersect_object(o, (0.999, 0.999, 0), (0, 0, 1), 1)
+    assert hit == 1
+    assert oracle.intersect_object(o, (1.001, 0, 0), (0, 0, 1), 1)[0] == 0       # outside the square
+    assert oracle.intersect_object(o, (0, 0, 0), (0, 0, -1), 1)[0] == 0          # behind the ray
+    assert oracle.intersect_object(o, (0, 0, 0), (1, 0, 0), 1)[0] == 0           # parallel: the reference's own line
+    assert oracle.intersect_object(o, (0, 0, 4.9995), (0, 0, 1), 1)[0] == 0      # t = 0.0005 <= 0.001
+    hit, t, n = oracle.intersect_object(o, (0, 0, 0), (0, 0, 1), 0)              # literal: normal never delivered (D2)
+    assert hit == 1 and t == 5.0 and n == [7.0, 7.0, 7.0]
+    s = oracle.Object()
+    s.type, s.size = 1, 2.0
+    for k, v in enumerate((0.0, 0.0, 6.0)):
+        s.position[k] = v
+    sp = oracle.Sphere()
+    sp.radius = 2.0
+    for k, v in enumerate((0.0, 0.0, 6.0)):
+        sp.center[k] = v
+    assert oracle.intersect_object(s, (0.1, 0.2, 0), (0, 0, 1), 1) == oracle.intersect(sp, (0.1, 0.2, 0), (0, 0, 1), 1)

@@ -1095,3 +1095,71 @@ def test_primary_hit_reuse_row_is_bit_identical_and_rejects_what_it_does_not_ser
     with pytest.raises(rtm.RtmError) as e:
         _gpu_image(rtm, data, "repaired", -1, 1, want=("f64",), variant=15)
     assert e.value.status == -8
+
+
+# ---- png::PlaneObject: a build-defined completion, oracle and device bit for bit -----------
+def _oracle_objects(oracle, data):
+    arr, n = data.objects_c()
+    return (oracle.Object * max(n, 1)).from_buffer_copy(bytes(arr)), n
+
+
+@pytest.mark.parametrize("mode", ["literal", "repaired"])
+def test_plane_intersect_batch_bit_exact(rtm, oracle, mode):
+    """Object::Intersect seam for planes and spheres mixed: 4 096 (ray, object) pairs — rays aimed inside,
+    at the rim of and past the square, grazing and from behind — against the oracle, hit / t / normal."""
+    rng = np.random.default_rng(31)
+    n = 4096
+    objs = (rtm._lib.rtm_object * n)()
+    org = rng.uniform(-6, 6, (n, 3))
+    tgt = np.empty((n, 3))
+    for i in range(n):
+        o = objs[i]
+        plane = i % 4 != 3
+        o.type = 2 if plane else 1
+        pos = rng.uniform(-4, 4, 3)
+        for k in range(3):
+            o.position[k] = pos[k]
+            o.up[k] = rng.normal()
+            o.target[k] = pos[k] + rng.normal()
+        o.width = float(rng.uniform(0.5, 6.0))
+        o.size = np.float32(rng.uniform(0.3, 3.0))
+        # aim: inside (u in [-0.5, 0.5] widths), at the rim (|u| ~ 0.5), outside, or anywhere
+        kind = i % 5
+        spread = (0.45, 0.5, 0.7, 0.5000001, 3.0)[kind] * (o.width if plane else 2 * o.size)
+        tgt[i] = pos + rng.uniform(-1, 1, 3) * spread
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::97] *= -1.0  # some rays point away
+    m = {"literal": 0, "repaired": 1}[mode]
+    hit, t, nrm = rtm.intersect_objects_batch(objs, org, d, mode=mode)
+    oo = (oracle.Object * n).from_buffer_copy(bytes(objs))
+    hits = 0
+    for i in range(n):
+        h, tt, nn = oracle.intersect_object(oo[i], org[i], d[i], m)
+        assert (h, tt) == (int(hit[i]), float(t[i])), i
+        assert np.array_equal(np.array(nn).view(np.uint64), nrm[i].view(np.uint64)), i
+        hits += h
+    assert 0.2 * n < hits < 0.8 * n
+
+
+@pytest.mark.parametrize("max_bounces", [8, -1])
+def test_plane_room_render_vs_oracle(rtm, oracle, max_bounces):
+    """scenes/planeRoom.json — six PlaneObject walls, a square lamp, two spheres — loaded by LoadData (objectType 2)
+    and rendered by the per-object kernel: the oracle's image and counters, bit for bit; the fast kernels refuse it."""
+    path = oracle.scene_path("planeRoom.json")
+    data = rtm.LoadData(path).data
+    assert sum(isinstance(o, rtm.PlaneObject) for o in data.object) == 6 and len(data.object) == 8
+    data.width, data.height, data.samples, data.superSamples = 96, 60, 4, 2
+    out, st = _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64", "u8"))
+    oobj, n = _oracle_objects(oracle, data)
+    ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
+    ref, cnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=1, max_bounces=max_bounces, seed=9, height=60))
+    assert _bits_equal(out["f64"], ref) and np.array_equal(out["u8"], oracle.quantise(ref))
+    assert {k: st[k] for k in ("samples", "casts", "bounces", "draws")} == {k: cnt[k] for k in ("samples", "casts", "bounces", "draws")}
+    assert st["variant"] == 1 and ref.max() > 0.5 and st["bounces"] > st["samples"]  # lit, and paths do bounce
+    lit, lst = _gpu_image(rtm, data, "literal", max_bounces, 9, want=("f64",))
+    lref, lcnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=0, max_bounces=max_bounces, seed=9, height=60))
+    assert _bits_equal(lit["f64"], lref) and lst["casts"] == lcnt["casts"]
+    with pytest.raises(rtm.RtmError) as e:
+        _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64",), variant=2)
+    assert e.value.status == -8
