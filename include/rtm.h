@@ -212,6 +212,11 @@ int rtm_render(const rtm_settings* settings, const rtm_sphere* spheres, size_t n
                const rtm_options* options, double* out_f64, float* out_f32, uint8_t* out_u8,
                rtm_stats* stats);
 
+/* The blocking render for a list of objects of any type (rtm_object: spheres and planes), HOST buffers. */
+int rtm_render_objects(const rtm_settings* settings, const rtm_object* objects, size_t n_objects,
+                       const rtm_options* options, double* out_f64, float* out_f32, uint8_t* out_u8,
+                       rtm_stats* stats);
+
 /* ---- per-ray seam: png::PathTracing (src/Renderer.cpp:57-117) for a batch of rays on device.
  * Ray i uses the RNG stream keyed (seed, pixel = i, sample = 0).  Host buffers.
  * org/dir: n*3 doubles; out_radiance: n*3; out_draws/out_casts: n (nullable). */

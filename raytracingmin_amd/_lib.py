@@ -86,6 +86,8 @@ SIGNATURES = {
                                     C.c_void_p, _P(rtm_stats)]),
     "rtm_render": (C.c_int, [_P(rtm_settings), C.c_void_p, C.c_size_t, _P(rtm_options),
                              C.c_void_p, C.c_void_p, C.c_void_p, _P(rtm_stats)]),
+    "rtm_render_objects": (C.c_int, [_P(rtm_settings), C.c_void_p, C.c_size_t, _P(rtm_options),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, _P(rtm_stats)]),
     "rtm_path_trace_batch": (C.c_int, [C.c_void_p, C.c_size_t, _P(rtm_options), C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_intersect_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,

@@ -79,6 +79,11 @@ int rtm_render(const rtm_settings* settings, const rtm_sphere* spheres, size_t n
                rtm_stats* stats) {
     RTM_GUARD(rtm::render_host(settings, spheres, n_spheres, options, out_f64, out_f32, out_u8, stats))
 }
+int rtm_render_objects(const rtm_settings* settings, const rtm_object* objects, size_t n_objects,
+                       const rtm_options* options, double* out_f64, float* out_f32, uint8_t* out_u8,
+                       rtm_stats* stats) {
+    RTM_GUARD(rtm::render_host_objects(settings, objects, n_objects, options, out_f64, out_f32, out_u8, stats))
+}
 int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options,
                          const double* org, const double* dir, size_t n_rays, double* out_radiance,
                          uint32_t* out_draws, uint32_t* out_casts) {

@@ -34,6 +34,8 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int sp
                   rtm_stats* stats);
 int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt,
                 double* out64, float* out32, uint8_t* out8, rtm_stats* stats);
+int render_host_objects(const rtm_settings* st, const rtm_object* objs, size_t n, const rtm_options* opt,
+                        double* out64, float* out32, uint8_t* out8, rtm_stats* stats);
 int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,
                      const double* dir, size_t n_rays, double* out, uint32_t* out_draws,
                      uint32_t* out_casts);

@@ -2328,6 +2328,35 @@ int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rt
     return rc;
 }
 
+int render_host_objects(const rtm_settings* st, const rtm_object* objs, size_t n, const rtm_options* opt,
+                        double* out64, float* out32, uint8_t* out8, rtm_stats* stats) {
+    int rc = validate(st, nullptr, 0, opt);
+    if (rc != RTM_OK) return rc;
+    rtm_scene* raw = nullptr;
+    rc = scene_create_objects(objs, n, opt->device, &raw);
+    if (rc != RTM_OK) return rc;
+    struct Destroy {
+        void operator()(rtm_scene* p) const { (void)scene_destroy(p); }
+    };
+    std::unique_ptr<rtm_scene, Destroy> scene(raw);
+    const size_t vals = (size_t)output_rows(opt) * st->width * 3;
+    DevMem d64, d32, d8;
+    rtm_stats local;
+    if (vals) {
+        if (out64 && (rc = d64.alloc(vals * sizeof(double))) != RTM_OK) return rc;
+        if (out32 && (rc = d32.alloc(vals * sizeof(float))) != RTM_OK) return rc;
+        if (out8 && (rc = d8.alloc(vals)) != RTM_OK) return rc;
+    }
+    rc = render_scene(st, scene.get(), opt, d64.as<double>(), d32.as<float>(), d8.as<uint8_t>(), nullptr, &local);
+    if (rc == RTM_OK && vals) {
+        if (out64) RTM_HIP_CHECK(hipMemcpy(out64, d64.p, vals * sizeof(double), hipMemcpyDeviceToHost));
+        if (out32) RTM_HIP_CHECK(hipMemcpy(out32, d32.p, vals * sizeof(float), hipMemcpyDeviceToHost));
+        if (out8) RTM_HIP_CHECK(hipMemcpy(out8, d8.p, vals, hipMemcpyDeviceToHost));
+    }
+    if (stats) *stats = local;
+    return rc;
+}
+
 int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,
                      const double* dir, size_t n_rays, double* out, uint32_t* out_draws,
                      uint32_t* out_casts) {

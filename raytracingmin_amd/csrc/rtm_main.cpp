@@ -96,13 +96,14 @@ int main(int argc, char* argv[]) {
     rtm_settings st;
     size_t n = 0;
     const int literal = (mode == RTM_MODE_LITERAL);
-    int rc = rtm_scene_load_json(json_file.c_str(), literal, &st, nullptr, 0, &n);
+    // the any-type object list: the shipped files hold spheres only; objectType 2 (png::PlaneObject) loads too
+    int rc = rtm_scene_load_json_objects(json_file.c_str(), literal, &st, nullptr, 0, &n);
     if (rc != RTM_OK) {
         std::fprintf(stderr, "%s: %s (%s)\n", json_file.c_str(), rtm_strerror(rc), rtm_last_error_detail());
         return 1;
     }
-    std::vector<rtm_sphere> spheres(n ? n : 1);
-    rc = rtm_scene_load_json(json_file.c_str(), literal, &st, spheres.data(), n, &n);
+    std::vector<rtm_object> spheres(n ? n : 1);
+    rc = rtm_scene_load_json_objects(json_file.c_str(), literal, &st, spheres.data(), n, &n);
     if (rc != RTM_OK) {
         std::fprintf(stderr, "%s: %s (%s)\n", json_file.c_str(), rtm_strerror(rc), rtm_last_error_detail());
         return 1;
@@ -140,7 +141,8 @@ int main(int argc, char* argv[]) {
             return 1;
         }
     } else {
-        rc = rtm_render(&st, spheres.data(), n, &opt, nullptr, rgb32.empty() ? nullptr : rgb32.data(), rgb8.data(), &stats);
+        rc = rtm_render_objects(&st, spheres.data(), n, &opt, nullptr, rgb32.empty() ? nullptr : rgb32.data(), rgb8.data(),
+                                &stats);
         if (rc != RTM_OK) {
             std::fprintf(stderr, "render failed: %s (%s)\n", rtm_strerror(rc), rtm_last_error_detail());
             return 1;

@@ -78,7 +78,7 @@ struct Comms {
 };
 }  // namespace
 
-int rtm_node_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n, const rtm_options* base,
+int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n, const rtm_options* base,
                     int n_devices, int virtual_strips, int force_rccl, float* out_f32_host, uint8_t* out_u8_host,
                     rtm_stats* total, std::string& err) {
     if (!st || !base || (!out_u8_host && !out_f32_host) || n_devices < 1) return RTM_ERR_INVALID_ARGUMENT;
@@ -106,9 +106,9 @@ int rtm_node_render(const rtm_settings* st, const rtm_sphere* spheres, size_t n,
         NODE_HIP(hipSetDevice(p.dev));
         NODE_HIP(hipStreamCreate(&p.stream));
         if (p.rows) NODE_HIP(hipMalloc((void**)&p.strip, p.rows * W * px_bytes));
-        const int rc = rtm_scene_create(spheres, n, 0, p.dev, &p.scene);
+        const int rc = rtm_scene_create_objects(objects, n, p.dev, &p.scene);
         if (rc != RTM_OK) {
-            err = std::string("rtm_scene_create: ") + rtm_last_error_detail();
+            err = std::string("rtm_scene_create_objects: ") + rtm_last_error_detail();
             return rc;
         }
     }

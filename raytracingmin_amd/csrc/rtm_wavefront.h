@@ -355,10 +355,22 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
     const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
     const double mag = R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max;  // bounds every fp32 intermediate
     const double m32 = 0x1p-20 * mag + 0x1p-110 * (1.0 + dd + e1 + R2);     // rounding + underflow
-    // magnitudes that could overflow single precision (or a non-finite ray): reject nothing
-    const float neg_margin = (mag < 0x1p100) ? -(float)((m32 + m64) * (1.0 + 0x1p-20)) : -HUGE_VALF;
+    // The per-ray constant k = (o.d)^2 - o.o never enters the per-sphere arithmetic: D4 >= -margin is tested as
+    //   (c.d)^2 + (c.e + w') >= -margin - k =: thr,
+    // one packed instruction per sphere pair fewer than adding k inside (8 -> 7).  thr is formed in fp64 and
+    // rounded DOWN to float (a threshold that is too low only lets more spheres through to the exact test);
+    // the margin carries 2 u |k| more for the value the sum would have had with k inside.
+    // Magnitudes that could overflow single precision (or a non-finite ray): reject nothing.
+    float neg_margin = -HUGE_VALF;
+    if (mag < 0x1p100) {
+        const double thr64 = -((m32 + m64 + 0x1p-23 * __builtin_fabs(kq)) * (1.0 + 0x1p-20)) - kq;
+        float thr = (float)thr64;
+        if ((double)thr > thr64) thr = __uint_as_float(thr > 0.f ? __float_as_uint(thr) - 1u :
+                                                     thr < 0.f ? __float_as_uint(thr) + 1u : 0x80000001u);  // next float below
+        neg_margin = thr;
+    }
     const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
-    const float ex = (float)e.x, ey = (float)e.y, ez = (float)e.z, kf = (float)kq;
+    const float ex = (float)e.x, ey = (float)e.y, ez = (float)e.z;
 
     typedef float f2 __attribute__((ext_vector_type(2)));
     struct Pair {
@@ -374,26 +386,25 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
             g[k].w = f2{q[8 * k + 6], q[8 * k + 7]};
         }
     };
-    const f2 dx2 = f2{dx, dx}, dy2 = f2{dy, dy}, dz2 = f2{dz, dz}, ex2 = f2{ex, ex}, ey2 = f2{ey, ey}, ez2 = f2{ez, ez},
-             kf2 = f2{kf, kf};
+    const f2 dx2 = f2{dx, dx}, dy2 = f2{dy, dy}, dz2 = f2{dz, dz}, ex2 = f2{ex, ex}, ey2 = f2{ey, ey}, ez2 = f2{ez, ez};
     auto test = [&](const Pair (&g)[K / 2], int j) {
         f2 tq[K / 2];
-        f2 top2 = f2{-HUGE_VALF, -HUGE_VALF};
+        f2 top2;
 #pragma unroll
         for (int k = 0; k < K / 2; ++k) {
             if constexpr (PACKED) {
                 const f2 uq = __builtin_elementwise_fma(g[k].z, dz2, __builtin_elementwise_fma(g[k].y, dy2, g[k].x * dx2));
                 const f2 vq = __builtin_elementwise_fma(g[k].z, ez2, __builtin_elementwise_fma(g[k].y, ey2,
-                                  __builtin_elementwise_fma(g[k].x, ex2, kf2))) + g[k].w;
+                                  __builtin_elementwise_fma(g[k].x, ex2, g[k].w)));
                 tq[k] = __builtin_elementwise_fma(uq, uq, vq);
             } else {
                 const float u0 = __builtin_fmaf(g[k].z.x, dz, __builtin_fmaf(g[k].y.x, dy, g[k].x.x * dx));
                 const float u1 = __builtin_fmaf(g[k].z.y, dz, __builtin_fmaf(g[k].y.y, dy, g[k].x.y * dx));
-                const float v0 = __builtin_fmaf(g[k].z.x, ez, __builtin_fmaf(g[k].y.x, ey, __builtin_fmaf(g[k].x.x, ex, kf))) + g[k].w.x;
-                const float v1 = __builtin_fmaf(g[k].z.y, ez, __builtin_fmaf(g[k].y.y, ey, __builtin_fmaf(g[k].x.y, ex, kf))) + g[k].w.y;
+                const float v0 = __builtin_fmaf(g[k].z.x, ez, __builtin_fmaf(g[k].y.x, ey, __builtin_fmaf(g[k].x.x, ex, g[k].w.x)));
+                const float v1 = __builtin_fmaf(g[k].z.y, ez, __builtin_fmaf(g[k].y.y, ey, __builtin_fmaf(g[k].x.y, ex, g[k].w.y)));
                 tq[k] = f2{__builtin_fmaf(u0, u0, v0), __builtin_fmaf(u1, u1, v1)};
             }
-            top2 = __builtin_elementwise_max(top2, tq[k]);  // v_pk_max_f32 skips NaN operands like v_max_f32
+            top2 = k ? __builtin_elementwise_max(top2, tq[k]) : tq[k];  // v_pk_max_f32 skips NaN operands like v_max_f32
         }
         const float top = __builtin_fmaxf(top2.x, top2.y);
         if (__builtin_amdgcn_ballot_w64(top >= neg_margin) == 0) return;

@@ -121,14 +121,17 @@ class Renderer:
             out["f32"] = np.zeros((rows, W, 3), dtype=np.float32)
         if "u8" in want:
             out["u8"] = np.zeros((rows, W, 3), dtype=np.uint8)
-        if self.data.has_planes():  # rtm_render takes sphere arrays; planes go through the scene handle
-            dev_out, self.stats = self.render_rows_device(row_begin, row_end, want=want, band=band)
-            return {k: v.cpu().numpy() for k, v in dev_out.items()}, self.stats
-        st, arr, n = self.data.to_c()
         s = rtm_stats()
         ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
-        _lib.check(_lib.lib().rtm_render(C.byref(st), arr, n, C.byref(opt), ptr("f64"), ptr("f32"),
-                                         ptr("u8"), C.byref(s)), "rtm_render")
+        if self.data.has_planes():  # rtm_render takes sphere arrays; any other object goes through rtm_render_objects
+            st = self.data.settings_c()
+            arr, n = self.data.objects_c()
+            _lib.check(_lib.lib().rtm_render_objects(C.byref(st), arr, n, C.byref(opt), ptr("f64"), ptr("f32"),
+                                                     ptr("u8"), C.byref(s)), "rtm_render_objects")
+        else:
+            st, arr, n = self.data.to_c()
+            _lib.check(_lib.lib().rtm_render(C.byref(st), arr, n, C.byref(opt), ptr("f64"), ptr("f32"),
+                                             ptr("u8"), C.byref(s)), "rtm_render")
         self.stats = s.as_dict()
         return out, self.stats
 

@@ -108,3 +108,22 @@ def test_cli_forced_rccl_gather_equals_plain_render(tmp_path, oracle):
     st, arr, n = oracle.load_scene(scene, width=88, height=50, samples=2, super_samples=2)
     ref, _ = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=8, seed=7, height=50))
     assert np.array_equal(f32.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+
+
+def test_cli_renders_a_scene_with_planes(tmp_path, oracle):
+    """scenes/planeRoom.json (objectType 2 = png::PlaneObject, the build-defined extension) through the host
+    program: the bytes of the oracle's quantised frame."""
+    from PIL import Image
+    import raytracingmin_amd as rtm
+    scene = oracle.scene_path("planeRoom.json")
+    stem = str(tmp_path / "room")
+    r = subprocess.run([CLI, "-json", scene, "--width", "80", "--height", "48", "--samples", "4", "--superSamples", "2",
+                        "--max-bounces", "8", "--seed", "5", "--out", stem], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = rtm.LoadData(scene).data
+    data.width, data.height, data.samples, data.superSamples = 80, 48, 4, 2
+    arr, n = data.objects_c()
+    oobj = (oracle.Object * n).from_buffer_copy(bytes(arr))
+    ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
+    ref, _ = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=1, max_bounces=8, seed=5, height=48))
+    assert np.array_equal(np.array(Image.open(stem + ".bmp")), oracle.quantise(ref))
