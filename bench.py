@@ -196,10 +196,23 @@ def main():
     if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line
+        # there, so stdout points at stderr until the group has done its first collective
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     host_trig = not args.device_trig
 
     cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
