@@ -849,6 +849,7 @@ __global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderPar
 
 }  // namespace rtm
 #include "rtm_wavefront.h"
+#include "rtm_fp32.h"
 namespace rtm {
 
 // ------------------------------------------------------------------------------------------------
@@ -1571,9 +1572,11 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       "fast-math-lds-tables-chunk8-park-pack8-immediate-fold",
                                       "fast-math-global-scene-chunk8-park-pack8",
                                       ("LABELLED-primary-hit-reuse (one nearest-hit search per sub-pixel for its S primary rays; "
-                                       "not the reference's work per sample)")};
+                                       "not the reference's work per sample)"),
+                                      ("LABELLED-fp32-fast (single precision, hardware sqrt/rsq/sin/cos, fused multiply-adds, "
+                                       "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)")};
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15;
+              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15, kVariantFp32 = 16;
 constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
@@ -1715,6 +1718,9 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
         } else {
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }
+    } else if (variant == kVariantFp32) {  // validated by render_view: repaired mode, 1 <= n <= 256
+        const size_t lds = (((size_t)n * kFp32Row * sizeof(float) + 15) & ~(size_t)15) + 10 * sizeof(double);
+        render_fp32_kernel<<<grid, 64, lds, stream>>>(P);
     } else if (variant == kVariantPrimaryReuse) {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
         const size_t lds = lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
                            kFoldQueueBytes + debug_lds_pad();
@@ -2153,6 +2159,10 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
             return RTM_ERR_UNSUPPORTED;
         }
         variant = kVariantRef;
+    }
+    if (variant == kVariantFp32 && !(n >= 1 && n <= 256 && P.mode == RTM_MODE_REPAIRED)) {
+        set_last_error("variant 16 (fp32 fast row) serves repaired-mode scenes of 1..256 spheres");
+        return RTM_ERR_UNSUPPORTED;
     }
     if (variant == kVariantPrimaryReuse &&
         !(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && P.max_bounces >= 0 && P.max_bounces <= 8)) {
