@@ -161,7 +161,8 @@ def other_configs(rtm, cfg, device, host_trig):
         "sphere_tests_per_s": tests_per_s,
         "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
         "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-        "note": "a 64-row strip fills the chip for fewer of its trips than the full frame does (profiles/)"}
+        "note": "a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the chip "
+                "(DESIGN.md §4); the full 1080p frame runs at 20.6 Msamples/s (profiles/r1/c5_full_frame_bench.json)"}
     return out
 
 

@@ -1982,7 +1982,8 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
         S.levels = (int)(budget < 64 ? 64 : (budget > 1024 ? 1024 : budget));
     }
     const size_t N = S.npix;
-    const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256;
+    const size_t part_bytes = (size_t)(kWfMaxParts - 1) * kWfPartSlots * 12 + 64;
+    const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256 + part_bytes;
     unsigned char* ws = nullptr;
     int rc = scratch_acquire(ctx, kScratchWavefront, bytes, (void**)&ws);
     if (rc != RTM_OK) return rc;
@@ -2007,6 +2008,10 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
     S.active[0] = (unsigned*)take(N * 4);
     S.active[1] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
+    S.part_t = (double*)take((size_t)(kWfMaxParts - 1) * kWfPartSlots * 8);
+    S.part_id = (int*)take((size_t)(kWfMaxParts - 1) * kWfPartSlots * 4);
+    S.part_slots = kWfPartSlots;
+    S.parts = 1;
     if (scalar_scene >= 2 && !P.scene.geom32) {
         set_last_error("scene without rejection-test data");
         return RTM_ERR_INVALID_ARGUMENT;
@@ -2038,10 +2043,18 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
         // read-back; long trips: one
         const int batch = ((unsigned long long)na * (unsigned long long)P.scene.n < 2000000000ull) ? 8 : 1;
         const unsigned g = (na + 255) / 256;
+        // few rays against a long list: cut the list so that rays x parts fills the chip (~16 waves per SIMD's worth)
+        int parts = 1;
+        if (scalar_scene == 3)
+            while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * parts * 2 <= (1ull << 20) &&
+                   P.scene.n / (parts * 2) >= 2048)
+                parts *= 2;
+        S.parts = parts;
+        S.part_blocks = g;
         for (int k = 0; k < batch; ++k, ++trip) {
             RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
             if (scalar_scene == 3)
-                wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 0, stream>>>(P, S, cur);
+                wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 0, stream>>>(P, S, cur);
             else if (scalar_scene == 2)
                 wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(P, S, cur);
             else if (scalar_scene == 1)

@@ -39,7 +39,19 @@ struct WfState {
     unsigned* n_active;  // [2]
     unsigned npix;
     int levels;
+    // Few active rays (a small frame, a strip, the tail of a frame): the sphere list is cut into `parts` ranges and
+    // every range gets its own blocks, so that the chip is filled by rays x ranges instead of idling at one or two
+    // waves per SIMD on a latency-bound scalar stream.  Part 0 writes hit_t / hit_id as always; part q >= 1 writes
+    // slot i of the active list into part_t / part_id[(q - 1) * part_slots + i]; the shade kernel takes the
+    // smallest t with strict < in part order — parts ascend in sphere index, so the lowest index still wins ties.
+    int parts;             // 0 or 1: no split
+    unsigned part_blocks;  // blocks per part (rays / 256)
+    unsigned part_slots;   // capacity of one part's slot arrays
+    double* part_t;
+    int* part_id;
 };
+constexpr unsigned kWfPartSlots = 1u << 19;  // the split is used only while the active list is this short
+constexpr int kWfMaxParts = 8;
 
 __device__ __forceinline__ void wf_pixel_xy(const RenderParams& P, unsigned p, int& x, int& y) {
     x = (int)(p % (unsigned)P.W);
@@ -328,8 +340,11 @@ template <class M, int BLOCK, int K, bool PACKED = true>
 __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParams P, const WfState S, const int cur) {
     static_assert(K == 4 || K == 8, "one or two 64-byte scalar loads per chunk");
     const unsigned na = S.n_active[cur];
-    if (blockIdx.x * (unsigned)BLOCK >= na) return;
-    const unsigned i = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+    const int parts = S.parts > 1 ? S.parts : 1;
+    const unsigned part = parts > 1 ? blockIdx.x / S.part_blocks : 0u;       // wave-uniform
+    const unsigned ray_block = parts > 1 ? blockIdx.x % S.part_blocks : blockIdx.x;
+    if (ray_block * (unsigned)BLOCK >= na) return;
+    const unsigned i = ray_block * (unsigned)BLOCK + threadIdx.x;
     const bool live = i < na;
     const unsigned N = S.npix;
     const unsigned p = S.active[cur][live ? i : na - 1];
@@ -418,30 +433,42 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         }
     };
 
-    const int n_pairs = n / (2 * K);
-    const int n_full = n_pairs * 2 * K;
+    // this block's range of the sphere list: all of it, or part `part` of `parts` (cut on chunk-pair boundaries)
+    const int n_pairs_all = n / (2 * K);
+    const int pairs_per = (n_pairs_all + parts - 1) / parts;
+    const int j_begin = (int)part * pairs_per * 2 * K;
+    const int j_end_full = ((int)part + 1 == parts) ? n_pairs_all * 2 * K
+                                                   : (((int)part + 1) * pairs_per < n_pairs_all ? ((int)part + 1) * pairs_per
+                                                                                              : n_pairs_all) * 2 * K;
     Pair a[K / 2], b[K / 2];
-    if (n_pairs > 0) load32(0, a);
-    for (int j = 0; j < n_full; j += 2 * K) {
+    if (j_begin < j_end_full) load32(j_begin, a);
+    for (int j = j_begin; j < j_end_full; j += 2 * K) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
         __builtin_amdgcn_sched_barrier(0);
         load32(j + K, b);
         __builtin_amdgcn_sched_barrier(0);
         test(a, j);
-        const int jn = (j + 2 * K < n_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
+        const int jn = (j + 2 * K < j_end_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
         __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
         __builtin_amdgcn_sched_barrier(0);
         load32(jn, a);
         __builtin_amdgcn_sched_barrier(0);
         test(b, j + K);
     }
-    for (int j = n_full; j < n; ++j) {
-        double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
-        sphere_chunk_g<M, 1, true>(g1, j, org, dir, dis, id);
+    if ((int)part + 1 == parts) {  // the spheres after the last full chunk pair belong to the last part
+        for (int j = n_pairs_all * 2 * K; j < n; ++j) {
+            double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
+            sphere_chunk_g<M, 1, true>(g1, j, org, dir, dis, id);
+        }
     }
     if (live) {
-        S.hit_id[p] = id;
-        S.hit_t[p] = dis;
+        if (part == 0u) {
+            S.hit_id[p] = id;
+            S.hit_t[p] = dis;
+        } else {
+            S.part_id[(size_t)(part - 1u) * S.part_slots + i] = id;
+            S.part_t[(size_t)(part - 1u) * S.part_slots + i] = dis;
+        }
     }
 }
 
@@ -471,8 +498,18 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderParams P, con
             else
                 overflow = true;
         };
+        // nearest hit over the parts of the sphere list (one part: what the search wrote)
+        int hit_id = S.hit_id[p];
+        double hit_t = S.hit_t[p];
+        for (int q = 1; q < S.parts; ++q) {  // wave-uniform count; ascending sphere index, strict <: lowest index wins ties
+            const int idq = S.part_id[(size_t)(q - 1) * S.part_slots + i];
+            const double tq = S.part_t[(size_t)(q - 1) * S.part_slots + i];
+            const bool better = idq >= 0 && tq < hit_t;
+            hit_id = better ? idq : hit_id;
+            hit_t = better ? tq : hit_t;
+        }
         D3 term;
-        bool cont = path_shade_spec(sc, S.hit_id[p], S.hit_t[p], P.mode, P.max_bounces, org, dir, depth, rng, term,
+        bool cont = path_shade_spec(sc, hit_id, hit_t, P.mode, P.max_bounces, org, dir, depth, rng, term,
                                     pc, push);
         if (cont && overflow) {
             cont = false;
