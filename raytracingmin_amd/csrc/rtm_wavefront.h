@@ -369,7 +369,10 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
     const double e1 = __builtin_fabs(e.x) + __builtin_fabs(e.y) + __builtin_fabs(e.z);
     const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
     const double mag = R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max;  // bounds every fp32 intermediate
-    const double m32 = 0x1p-20 * mag + 0x1p-110 * (1.0 + dd + e1 + R2);     // rounding + underflow
+    // rounding (u = 2^-24; the derived constants are 11.7, 6.0 and 5.0 for the form with k outside the sum — DESIGN.md,
+    // appendix — rounded up; round 1 used 16 for every term: twice the margin.  Halving it did not change the time: the
+    // chunks that escalate do so because some lane's ray really has D4 >= 0 for one of their spheres) + underflow
+    const double m32 = 0x1p-24 * (12.0 * (R2 * dd) + 7.0 * (R * e1) + 6.0 * (R2 + r2max)) + 0x1p-110 * (1.0 + dd + e1 + R2);
     // The per-ray constant k = (o.d)^2 - o.o never enters the per-sphere arithmetic: D4 >= -margin is tested as
     //   (c.d)^2 + (c.e + w') >= -margin - k =: thr,
     // one packed instruction per sphere pair fewer than adding k inside (8 -> 7).  thr is formed in fp64 and
