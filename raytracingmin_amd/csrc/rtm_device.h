@@ -242,6 +242,13 @@ __host__ __device__ __forceinline__ double rng_next(RngStream& s) {
     s.ctr += 0x9E3779B9u;
     return rng_bits_to_u01(x);
 }
+// The draw as the odd integer m = 2 (bits >> 9) + 1 < 2^24 in a double: u = m * 2^-24.  Callers that only compare u
+// with a constant, or scale it by one, fold the 2^-24 into the constant (exact: a power of two) and save the ldexp.
+__host__ __device__ __forceinline__ double rng_next_m(RngStream& s) {
+    const uint32_t x = mix32(s.ctr ^ s.k1);
+    s.ctr += 0x9E3779B9u;
+    return (double)(2u * (x >> 9) + 1u);
+}
 __host__ __device__ __forceinline__ double rng_u01_at(uint64_t seed_mult, uint32_t pixel, uint32_t sample,
                                                       uint32_t index) {
     RngStream s = rng_open(rng_pixel_key(seed_mult, pixel), sample);

@@ -122,8 +122,9 @@ struct RecordStack {
 };
 
 // LDS copy of the scene tables: n geometry rows (4 doubles) + n+1 material rows (8 doubles, the last
-// one is the identity row) + n normal-length rows (2 doubles)
-__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 6 + ((size_t)n + 1) * 8) * sizeof(double); }
+// one is the identity row) + n normal-length rows (3 doubles: |hit - centre| as Magnitude returns it, its refined
+// reciprocal, and the float r*r in the low word of the third)
+__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 7 + ((size_t)n + 1) * 8) * sizeof(double); }
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
 __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
@@ -266,8 +267,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
         for (int i = lane; i < P.scene.n; i += 64) {
             const double ms = (double)__builtin_sqrtf((float)gsrc[i * 4 + 3]);
-            lnrm[i * 2] = ms;
-            lnrm[i * 2 + 1] = refined_rcp_or_nan(ms);
+            lnrm[i * 3] = ms;
+            lnrm[i * 3 + 1] = refined_rcp_or_nan(ms);
+            reinterpret_cast<float*>(lnrm + i * 3 + 2)[0] = (float)gsrc[i * 4 + 3];  // r*r as the float it is
         }
         __syncthreads();  // one wave per block: orders the LDS writes before the reads
     }
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     const bool capped = P.max_bounces >= 0 && depth >= P.max_bounces;
                     drew = id >= 0 && !capped;
                     bool rr_pass = false;
-                    if (drew) rr_pass = rng_next(rng) <= sc.kd(id);  // :78
+                    if (drew) rr_pass = rng_next_m(rng) <= sc.kd24(id);  // :78
                     ends = !rr_pass;
                     settled = rr_pass;
                     if (ends) {
@@ -1140,7 +1142,7 @@ static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& g
         mat[i * 8 + 4] = sp[i].emission[1];
         mat[i * 8 + 5] = sp[i].emission[2];
         mat[i * 8 + 6] = kd;
-        mat[i * 8 + 7] = 0.0;
+        mat[i * 8 + 7] = kd * 16777216.0;  // kd * 2^24 (exact): the RR test compares it with the draw's integer
     }
 }
 
@@ -1167,7 +1169,7 @@ __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n
     mat[i * 8 + 4] = sp[i].emission[1];
     mat[i * 8 + 5] = sp[i].emission[2];
     mat[i * 8 + 6] = kd;
-    mat[i * 8 + 7] = 0.0;
+    mat[i * 8 + 7] = kd * 16777216.0;
 }
 
 // ---- RAII for everything the host side owns: an early return (RTM_HIP_CHECK) releases it -------

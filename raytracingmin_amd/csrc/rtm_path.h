@@ -197,6 +197,18 @@ struct MathSpec {
         const double d1 = __builtin_fma(-s2, s2, x);
         return __builtin_fma(d1, h1, s2);
     }
+    // sqrt of an operand KNOWN to be a positive normal number of moderate size (r2 and 1 - r2 of a 23-bit draw:
+    // [2^-24, 1)): the unscaled sequence without its range check
+    __device__ __forceinline__ double sqrt64_unit(double x) {
+        const double y = __builtin_amdgcn_rsq(x);
+        const double s0 = x * y, h0 = 0.5 * y;
+        const double r0 = __builtin_fma(-h0, s0, 0.5);
+        const double s1 = __builtin_fma(s0, r0, s0), h1 = __builtin_fma(h0, r0, h0);
+        const double d0 = __builtin_fma(-s1, s1, x);
+        const double s2 = __builtin_fma(d0, h1, s1);
+        const double d1 = __builtin_fma(-s2, s2, x);
+        return __builtin_fma(d1, h1, s2);
+    }
     __device__ __forceinline__ D3 div3(D3 a, double y) {
         bad = bad || !(MathFast::moderate(y) && MathFast::moderate(a.x) && MathFast::moderate(a.y) &&
                        MathFast::moderate(a.z));
@@ -245,10 +257,12 @@ struct MathSpec {
         r = __builtin_fma(r, e, r);
         e = __builtin_fma(-y, r, 1.0);
         r = __builtin_fma(r, e, r);
+        // no v_div_fixup: with a non-zero, non-tiny, finite numerator and a denominator in [2^-48, 2^64) it returns
+        // its first operand (it only rewrites zeros, infinities, NaNs and results outside the exponent range)
         auto one = [&](double x) {
             const double q = x * r;
             const double rem = __builtin_fma(-y, q, x);
-            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+            return __builtin_fma(rem, r, q);
         };
         return D3{one(a.x), one(a.y), one(a.z)};
     }
@@ -301,10 +315,10 @@ struct MathSpec {
         r = __builtin_fma(r, e, r);
         e = __builtin_fma(-y, r, 1.0);
         r = __builtin_fma(r, e, r);
-        auto one = [&](double x) {
+        auto one = [&](double x) {  // no v_div_fixup: see div3_by_magnitude
             const double q = x * r;
             const double rem = __builtin_fma(-y, q, x);
-            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+            return __builtin_fma(rem, r, q);
         };
         ux = one(cx);
         uz = one(cz);
@@ -340,7 +354,11 @@ struct MathSpec {
         auto one = [&](double x) {
             const double q = x * rinv;
             const double rem = __builtin_fma(-ms, q, x);
+#if RTM_OPT_GUARD
+            return __builtin_fma(rem, rinv, q);  // no v_div_fixup: see div3_by_magnitude
+#else
             return __builtin_amdgcn_div_fixup(__builtin_fma(rem, rinv, q), ms, x);
+#endif
         };
         return D3{one(dv.x), one(dv.y), one(dv.z)};
     }
@@ -362,6 +380,7 @@ struct MathRefI {
     __device__ __forceinline__ D3 normalize(D3 a) { return MathRef::div3(a, magnitude(a)); }
     __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathRef::sqrt64(x); }
+    __device__ __forceinline__ double sqrt64_unit(double x) { return MathRef::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathRef::div3(a, y); }
     // r1 = 2*pi*u < 2^30 always: ocml's small-argument sequence IS ::sincos there (bit-identical)
     __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) {
@@ -376,6 +395,7 @@ struct MathFastI {
     __device__ __forceinline__ D3 normalize(D3 a) { return MathFast::div3(a, magnitude(a)); }
     __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathFast::sqrt64(x); }
+    __device__ __forceinline__ double sqrt64_unit(double x) { return MathFast::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathFast::div3(a, y); }
     __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
 };
@@ -479,6 +499,7 @@ struct SceneGlobal {
         return D3{g.x, g.y, g.z};
     }
     __device__ __forceinline__ double kd(int id) const { return v.mat[(size_t)id * 8 + 6]; }
+    __device__ __forceinline__ double kd24(int id) const { return v.mat[(size_t)id * 8 + 7]; }  // kd * 2^24
     __device__ __forceinline__ D3 emission(int id) const {
         const double* m = v.mat + (size_t)id * 8;
         return D3{m[3], m[4], m[5]};
@@ -495,12 +516,12 @@ struct SceneLds {
     SceneView v;
     const double* lgeom;  // LDS, 4 doubles per sphere
     const double* lmat;   // LDS, 8 doubles per sphere
-    const double* lnrm;   // LDS, 2 doubles per sphere: |hit - centre| as Magnitude returns it for a point
-                          // on the sphere, (double)sqrtf((float)(r*r)), and its refined reciprocal
+    const double* lnrm;   // LDS, 3 doubles per sphere: |hit - centre| as Magnitude returns it for a point
+                          // on the sphere, (double)sqrtf((float)(r*r)), its refined reciprocal, the float r*r
     static constexpr bool kHasNormTable = true;
-    __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 2]; }
-    __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 2 + 1]; }
-    __device__ __forceinline__ float norm_r2f(int id) const { return (float)lgeom[id * 4 + 3]; }
+    __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 3]; }
+    __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 3 + 1]; }
+    __device__ __forceinline__ float norm_r2f(int id) const { return reinterpret_cast<const float*>(lnrm + id * 3 + 2)[0]; }
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -508,6 +529,7 @@ struct SceneLds {
         return D3{g[0], g[1], g[2]};
     }
     __device__ __forceinline__ double kd(int id) const { return lmat[id * 8 + 6]; }
+    __device__ __forceinline__ double kd24(int id) const { return lmat[id * 8 + 7]; }
     __device__ __forceinline__ D3 emission(int id) const {
         const double* m = lmat + id * 8;
         return D3{m[3], m[4], m[5]};
@@ -749,7 +771,9 @@ __device__ __forceinline__ bool path_shade_core(MI& m, const Scene& sc, const in
         return false;
     }
     out.draws = 1;
-    if (!(rng_next(rng) <= sc.kd(id))) {  // :78, kd() is a float widened to double
+    // :78, kd() is a float widened to double.  u <= kd  <=>  m <= kd * 2^24 with u = m * 2^-24 (both sides scaled by
+    // an exact power of two)
+    if (!(rng_next_m(rng) <= sc.kd24(id))) {
         term = emission;                  // :112
         return false;
     }
@@ -782,13 +806,14 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));
     const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
     out.draws = 3;
-    const double r1 = 6.283185307179586 * rng_next(rng);  // :88  (2*PI folded)
+    // :88 r1 = 2 PI u with u = m * 2^-24: (2 PI * 2^-24) * m is the same correctly rounded product as 2 PI * (m * 2^-24)
+    const double r1 = (6.283185307179586 * 0x1p-24) * rng_next_m(rng);
     const double r2 = rng_next(rng);                      // :89
 #if RTM_OPT_TRIGLOAD
     TrigFixWord fixw{0u, 0};
     if (sc.v.trig_fix) fixw = trig_fix_load(sc.v.trig_fix, rng);  // wave-uniform; consumed after the sincos
 #endif
-    const double r2s = m.sqrt64(r2);                      // :90
+    const double r2s = m.sqrt64_unit(r2);                 // :90
     // :96-101 — one Normalize on the selected cross product (same values as the two-armed if)
     const bool use_y = fabs(w.x) > (double)FLT_MIN;
     const bool some_x_axis = __builtin_amdgcn_ballot_w64(!use_y) != 0;  // some lane has |w.x| <= FLT_MIN (e.g. literal mode)
@@ -814,7 +839,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
 #else
             if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);
 #endif
-            const double s1 = m.sqrt64(1.0 - r2);
+            const double s1 = m.sqrt64_unit(1.0 - r2);
             out.dir = normalize_i(m, d3(((ux * cs) * r2s + (vx * sn) * r2s) + w.x * s1, (vy * sn) * r2s + w.y * s1,
                                         ((uz * cs) * r2s + (vz * sn) * r2s) + w.z * s1));  // :103-107
             out.org = hit_point;
@@ -839,7 +864,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
 #else
     if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);  // wave-uniform
 #endif
-    out.dir = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64(1.0 - r2));  // :103-107
+    out.dir = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64_unit(1.0 - r2));  // :103-107
     out.org = hit_point;
     out.ctr = rng.ctr;
 }
