@@ -374,12 +374,18 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if (__builtin_amdgcn_ballot_w64(mine) == 0) break;
             if (mine) {
                 if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
+                    // One 32-byte cell per (sample, lane), layout [tile][sample][lane]: an aligned sector per store.  The 8-byte
+                    // stores into three 512-byte rows of round 1 were read-modify-written (PMC: 11.0 GB fetched and 8.8 GB
+                    // written for 3.2 GB of terms).  Measured (profiles/r2/split_layouts.txt): writes are now exactly the 4.2 GB
+                    // stored, fetches fell from 11.0 to 7.9 GB — stores leave L2 as they come, so a 32-byte store is still
+                    // completed to the memory's 64-byte granule there; [tile][lane][sample] (a lane's samples adjacent) was
+                    // no better (8.5 GB).  Only whole-line stores by one instruction would end that (entries written in
+                    // fold order by the folding lanes, reordered by the finalize kernel): not built, the kernel is not
+                    // bound by this traffic (~0.6 TB/s).
                     const unsigned tile = blockIdx.x % P.n_tiles;
-                    double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_head) * 192;
-                    const unsigned o = ((n - pend) - P.split_head) * 192u + (unsigned)lane;  // n - pend: this entry's sample
-                    row[o] = fq_out[0 * 64 + rel];
-                    row[o + 64] = fq_out[1 * 64 + rel];
-                    row[o + 128] = fq_out[2 * 64 + rel];
+                    double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)tile * (P.total_samples - P.split_head) * 64;
+                    const unsigned s_rel = (n - pend) - P.split_head;  // n - pend: this entry's sample
+                    cells[(size_t)s_rel * 64 + lane] = double4{fq_out[0 * 64 + rel], fq_out[1 * 64 + rel], fq_out[2 * 64 + rel], 0.0};
                 } else {
                     park[0 * 64 + lane] += fq_out[0 * 64 + rel];
                     park[1 * 64 + lane] += fq_out[1 * 64 + rel];
@@ -612,11 +618,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             const D3 add = clamp01_d3(cal);
             if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
                 const unsigned tile = blockIdx.x % P.n_tiles;
-                double* row = P.contrib + (size_t)tile * (P.total_samples - P.split_head) * 192;
-                const unsigned o = (n - P.split_head) * 192u + (unsigned)lane;
-                row[o] = add.x;
-                row[o + 64] = add.y;
-                row[o + 128] = add.z;
+                double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)tile * (P.total_samples - P.split_head) * 64;
+                cells[(size_t)(n - P.split_head) * 64 + lane] = double4{add.x, add.y, add.z, 0.0};
             } else if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
                 park[0 * 64 + lane] += add.x;
                 park[1 * 64 + lane] += add.y;
@@ -695,28 +698,27 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 }
 
 // Second half of a SPLIT render: image[pixel] = (((partial + term[split_head]) + term[split_head+1]) + ...),
-// the accumulation order of src/Renderer.cpp:241-242.  One wave per tile; the loads are 512-byte rows
-// and independent of the adds, so the kernel streams P.contrib at HBM rate (1536 B per pixel sample).
+// the accumulation order of src/Renderer.cpp:241-242.  One wave per tile; the loads are 2-KB rows of 32-byte cells
+// (one per lane), independent of the adds.
 __global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P) {
     const int lane = threadIdx.x;
     const unsigned tile = blockIdx.x;
     const double* part = P.partial + (size_t)tile * 192 + lane;
     D3 acc = d3(part[0], part[64], part[128]);
     const unsigned ns = P.total_samples - P.split_head;
-    const double* row = P.contrib + (size_t)tile * ns * 192 + lane;
+    const double4* cells = reinterpret_cast<const double4*>(P.contrib) + (size_t)tile * ns * 64 + lane;
     unsigned m = 0;
     for (; m + 8 <= ns; m += 8) {
-        double v[8][3];
+        double4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k][0] = row[(size_t)(m + k) * 192];
-            v[k][1] = row[(size_t)(m + k) * 192 + 64];
-            v[k][2] = row[(size_t)(m + k) * 192 + 128];
-        }
+        for (int k = 0; k < 8; ++k) v[k] = cells[(size_t)(m + k) * 64];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = acc + d3(v[k][0], v[k][1], v[k][2]);
+        for (int k = 0; k < 8; ++k) acc = acc + d3(v[k].x, v[k].y, v[k].z);
     }
-    for (; m < ns; ++m) acc = acc + d3(row[(size_t)m * 192], row[(size_t)m * 192 + 64], row[(size_t)m * 192 + 128]);
+    for (; m < ns; ++m) {
+        const double4 v = cells[(size_t)m * 64];
+        acc = acc + d3(v.x, v.y, v.z);
+    }
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const int px = tx * 8 + (lane & 7), py = band_row(P, ty, lane >> 3);
     store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
@@ -1933,7 +1935,7 @@ int release_scratch(int device) {
 // launch is cut finer: the result is the GRANULARITY g — small waves trace 1/g of a pixel's samples, and
 // (render_device) wave 0 of a tile takes half of them when g >= 4.  1/16 is the measured sweet spot for
 // one-eighth to one-half of a 1080p frame (profiles/r1/band_split_sweep_final.json); short sample counts
-// and the term buffer (1536 B per tile-sample that is not wave 0's, at most 24 GiB) cap it.
+// and the term buffer (2048 B per tile-sample that is not wave 0's, at most 24 GiB) cap it.
 static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
     static const long env = [] {
         const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, g = that granularity
@@ -1945,7 +1947,7 @@ static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int devic
     auto fits = [&](unsigned g) {
         if (g < 2 || total_samples % g != 0 || total_samples / g < 8) return false;
         const unsigned head = g >= 4 ? total_samples / 2 : total_samples / g;
-        const double per_tile = (double)(total_samples - head) * 1536.0;
+        const double per_tile = (double)(total_samples - head) * 2048.0;  // 64 lanes x 32-byte cells per deferred sample
         return (double)n_tiles * per_tile <= 24.0 * 1024 * 1024 * 1024 && per_tile < 4.0e9;
     };
     if (env > 0) return (env > 1 && fits((unsigned)env)) ? (unsigned)env : 1u;
@@ -2196,7 +2198,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
             P.split_len = P.total_samples / P.split;
             P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
-            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 192;
+            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 256;
             rc = scratch_acquire(ctx, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
             if (rc != RTM_OK) return rc;
             P.partial = split_ws;
