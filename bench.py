@@ -218,6 +218,7 @@ def main():
     if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # N GPUs of ONE node: RCCL's bootstrap over loopback
         # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line
         # there, so stdout points at stderr until the group has done its first collective
         sys.stdout.flush()

@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -145,6 +146,9 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
         for (int r = 0; r < parts; ++r) src[r] = part[r].strip;
     } else {
         NODE_HIP(hipMalloc((void**)&rb.stage, stage_off[parts] ? stage_off[parts] : 1));
+        // one process, one node: RCCL's bootstrap needs no more than the loopback interface (a container's veth is
+        // not always usable for it); an NCCL_SOCKET_IFNAME the user has set is respected
+        (void)setenv("NCCL_SOCKET_IFNAME", "lo", 0);
         Comms comms;
         comms.c.assign(parts, nullptr);
         std::vector<int> devs(parts);

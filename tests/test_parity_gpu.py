@@ -1190,3 +1190,96 @@ def test_fp32_row_statistics(rtm, oracle):
     with pytest.raises(rtm.RtmError) as e:                                 # literal semantics are an fp64 affair
         _gpu_image(rtm, data, "literal", mb, 1, want=("f64",), variant=16)
     assert e.value.status == -8
+
+
+def test_scene_entry_points_agree(rtm, oracle):
+    """The ways a scene reaches the kernels give the same frame: an rtm_scene made from a host array, one made from
+    a DEVICE-resident array (flattened by a kernel), rtm_render_device with a host array (content-addressed cache,
+    first call and a cached call), with a device array (stream-ordered temporaries), and the blocking rtm_render.
+    Ten different scenes in a row push the first ones out of the 8-entry cache and every frame is still right."""
+    import torch
+    L = rtm.lib()
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    data = rtm.LoadData(scene).data
+    data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 2
+    st = data.settings_c()
+    arr, n = data.spheres_c()
+    ost, oarr, on = oracle.load_scene(scene, width=72, height=40, samples=4, super_samples=2)
+    ref, _ = oracle.render(ost, oarr, on, oracle.make_options(mode=1, max_bounces=8, seed=3, height=40))
+    opt = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3)._options(0, 40)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_arr = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()  # the rtm_sphere array in device memory
+
+    def frame(call):
+        out = torch.empty((40, 72, 3), dtype=torch.float64, device="cuda")
+        stats = rtm._lib.rtm_stats()
+        rtm._lib.check(call(C.c_void_p(out.data_ptr()), C.byref(stats)), "render")
+        return out.cpu().numpy()
+
+    h_host, h_dev = C.c_void_p(), C.c_void_p()
+    rtm._lib.check(L.rtm_scene_create(arr, n, 0, 0, C.byref(h_host)), "rtm_scene_create")
+    rtm._lib.check(L.rtm_scene_create(C.c_void_p(d_arr.data_ptr()), n, 1, 0, C.byref(h_dev)), "rtm_scene_create(device)")
+    assert L.rtm_scene_size(h_host) == n == L.rtm_scene_size(h_dev)
+    frames = [
+        frame(lambda o, s: L.rtm_render_scene(C.byref(st), h_host, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_scene(C.byref(st), h_dev, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_device(C.byref(st), C.c_void_p(d_arr.data_ptr()), n, 1, C.byref(opt), o, None, None,
+                                               stream, s)),
+    ]
+    for f in frames:
+        assert _bits_equal(f, ref)
+    assert L.rtm_scene_destroy(h_host) == 0 and L.rtm_scene_destroy(h_dev) == 0 and L.rtm_scene_destroy(None) == 0
+    # ten different scenes through the array entry point: more than the cache holds
+    host = np.zeros((40, 72, 3), dtype=np.float64)
+    for k in range(10):
+        data.object[0].m_size = 5.0 + 0.25 * k
+        arr_k, n_k = data.spheres_c()
+        oarr_k = (oracle.Sphere * n_k).from_buffer_copy(bytes(arr_k))
+        want, _ = oracle.render(ost, oarr_k, n_k, oracle.make_options(mode=1, max_bounces=8, seed=3, height=40))
+        rtm._lib.check(L.rtm_render(C.byref(st), arr_k, n_k, C.byref(opt), host.ctypes.data, None, None, None), "rtm_render")
+        assert _bits_equal(host, want), k
+    rtm._lib.check(L.rtm_render(C.byref(st), arr, n, C.byref(opt), host.ctypes.data, None, None, None), "rtm_render")  # evicted, re-uploaded
+    assert _bits_equal(host, ref)
+
+
+def test_renders_on_two_streams_from_two_threads(rtm, oracle):
+    """Different (device, stream) pairs share nothing: two host threads, each with its own stream, scene handle and
+    frame size, render concurrently; every frame equals the oracle's."""
+    import threading
+    import torch
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    jobs = [(96, 56, 4, 2, 8, 31), (64, 80, 8, 1, -1, 32)]
+    want = []
+    for w, h, s, ss, mb, seed in jobs:
+        st, arr, n = oracle.load_scene(scene, width=w, height=h, samples=s, super_samples=ss)
+        want.append(oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=mb, seed=seed, height=h))[0])
+    got, errors = [[] for _ in jobs], []
+    streams = [torch.cuda.Stream() for _ in jobs]
+
+    def work(j):
+        try:
+            w, h, s, ss, mb, seed = jobs[j]
+            data = rtm.LoadData(scene).data
+            data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+            r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=seed)
+            with torch.cuda.stream(streams[j]):
+                for _ in range(5):
+                    out, _ = r.render_rows_device(want=("f64",), stats=False, stream=streams[j].cuda_stream)
+                    got[j].append(out["f64"])
+                streams[j].synchronize()
+                r.stream_status(streams[j].cuda_stream)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    for j in range(len(jobs)):
+        assert len(got[j]) == 5
+        for f in got[j]:
+            assert _bits_equal(f.cpu().numpy(), want[j]), j
