@@ -2058,7 +2058,7 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
         for (int k = 0; k < batch; ++k, ++trip) {
             RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
             if (scalar_scene == 3)
-                wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 0, stream>>>(P, S, cur);
+                wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
             else if (scalar_scene == 2)
                 wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(P, S, cur);
             else if (scalar_scene == 1)
@@ -2638,7 +2638,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
         P.scene.wprime = aux + 4;
         P.scene.geom32 = g32;
         if (kind == 3)
-            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256>>>(P, S, 0);
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 256 * kWfCandCap * sizeof(unsigned)>>>(P, S, 0);
         else
             wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);
     } else if (kind == 1) {

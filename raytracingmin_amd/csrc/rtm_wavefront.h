@@ -50,6 +50,7 @@ struct WfState {
     double* part_t;
     int* part_id;
 };
+constexpr int kWfCandCap = 16;               // candidate slots per lane of wf_nearest_f32_kernel (LDS: 4 B x BLOCK each)
 constexpr unsigned kWfPartSlots = 1u << 19;  // the split is used only while the active list is this short
 constexpr int kWfMaxParts = 8;
 
@@ -405,6 +406,30 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         }
     };
     const f2 dx2 = f2{dx, dx}, dy2 = f2{dy, dy}, dz2 = f2{dz, dz}, ex2 = f2{ex, ex}, ey2 = f2{ey, ey}, ez2 = f2{ez, ez};
+    // per-lane candidate lists in LDS, [slot][thread] (conflict-free: a slot is one dword per thread)
+    extern __shared__ unsigned cand[];
+    int cnt = 0;
+    // settle every lane's candidates with the reference's arithmetic (src/SettingData.cpp:197-226 + the caller's
+    // acceptance, select form — sphere_update), each lane walking ITS list in the order it was noted = index order, so
+    // strict < still lets the lowest index win ties
+    auto drain = [&]() {
+        for (int e = 0; __builtin_amdgcn_ballot_w64(e < cnt) != 0; ++e) {
+            if (e < cnt) {
+                const int jj = (int)cand[e * BLOCK + threadIdx.x];
+                const double4 g = P.scene.geom[jj];
+                const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // :198
+                const double b = dot(p_o, dir);                            // :199
+                const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200
+                const double sq = M::sqrt64(D4);                           // :205 (D4 < 0: NaN, nothing is accepted)
+                const double t1 = b - sq, t2 = b + sq;
+                const double t = (t1 > 0.001) ? t1 : t2;
+                const bool accept = (t < dis) && !(t < (double)1e-5f);
+                dis = accept ? t : dis;
+                id = accept ? jj : id;
+            }
+        }
+        cnt = 0;
+    };
     auto test = [&](const Pair (&g)[K / 2], int j) {
         f2 tq[K / 2];
         f2 top2;
@@ -426,14 +451,20 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         }
         const float top = __builtin_fmaxf(top2.x, top2.y);
         if (__builtin_amdgcn_ballot_w64(top >= neg_margin) == 0) return;
-        // rare: the spheres some lane could not reject get the reference arithmetic, in index order
+        // rare (~6 % of the chunks): a sphere some lane could not reject.  It is not settled here, where the exact
+        // arithmetic would run in all 64 lanes for the one that needs it (a quarter of the kernel's VALU work before),
+        // but noted in THAT lane's candidate list; the lists are settled 64 lanes at a time, in index order (drain).
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float t = (k & 1) ? tq[k / 2].y : tq[k / 2].x;
-            if (__builtin_amdgcn_ballot_w64(!(t < neg_margin)) == 0) continue;
-            double4 g64[1] = {load_geom_uniform(P.scene.geom, j + k)};
-            sphere_chunk_g<M, 1, true>(g64, j + k, org, dir, dis, id);
+            const bool pass = !(t < neg_margin);
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+            if (pass) {
+                cand[cnt * BLOCK + threadIdx.x] = (unsigned)(j + k);
+                ++cnt;
+            }
         }
+        if (__builtin_amdgcn_ballot_w64(cnt > kWfCandCap - K) != 0) drain();  // the next chunk might not fit
     };
 
     // this block's range of the sphere list: all of it, or part `part` of `parts` (cut on chunk-pair boundaries)
@@ -458,6 +489,7 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         __builtin_amdgcn_sched_barrier(0);
         test(b, j + K);
     }
+    drain();
     if ((int)part + 1 == parts) {  // the spheres after the last full chunk pair belong to the last part
         for (int j = n_pairs_all * 2 * K; j < n; ++j) {
             double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
