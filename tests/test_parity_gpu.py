@@ -482,6 +482,38 @@ def test_stress_scene_vs_oracle(rtm, oracle, n, w, h, s):
         assert np.array_equal(out["f64"].view(np.uint64), base.view(np.uint64))
 
 
+def test_large_scene_long_candidate_lists(rtm, oracle):
+    """The large-scene pipeline notes the spheres a lane could not reject in per-lane candidate lists of 16 slots and
+    settles them with the reference's arithmetic (csrc/rtm_wavefront.h, src/SettingData.cpp:197-226).  Nested shells
+    around the light put hundreds of candidates on every ray through the centre — the lists fill many times per
+    sweep — with exact ties among them (every 7th shell repeats the radius of its predecessor: the lowest index must
+    win, src/Renderer.cpp:67) and the true nearest hit anywhere in index order."""
+    rng = np.random.default_rng(77)
+    cam = rtm.Camera(rtm.vec3(0, 0, -30), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.0)
+    objs = []
+    r = 1.0
+    for k in range(620):
+        if k % 7 != 6:
+            r = float(rng.uniform(0.5, 6.0))
+        c = rng.uniform(-0.3, 0.3, 3) if k % 3 else np.zeros(3)
+        col = rng.uniform(0.3, 0.9, 3)
+        em = (4.0, 3.0, 2.0) if k % 50 == 0 else (0.0, 0.0, 0.0)
+        objs.append(rtm.SphereObject(rtm.vec3(*map(float, c)), r, rtm.Material(rtm.vec3(*map(float, col)), rtm.vec3(*em))))
+    objs.append(rtm.SphereObject(rtm.vec3(0, 0, 0), 60.0, rtm.Material(rtm.vec3(0.7, 0.7, 0.7), rtm.vec3(0.5, 0.5, 0.5))))
+    data = rtm.SettingData(width=40, height=24, samples=4, superSamples=1, camera=cam, object=objs)
+    st, arr, n = data.to_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=6, seed=9, height=24))
+    seen = set()
+    for v in _variants(rtm, data, 6):
+        out, stats = _gpu_image(rtm, data, "repaired", 6, 9, want=("f64",), variant=v)
+        seen.add(stats["variant"])
+        assert np.array_equal(out["f64"].view(np.uint64), ref.view(np.uint64)), f"variant {v}"
+        assert (stats["casts"], stats["bounces"], stats["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"])
+    assert 12 in seen  # the packed-fp32 rejection pipeline with the candidate lists took part
+
+
 def test_coincident_spheres_lowest_index_wins(rtm, oracle):
     """Exact ties (the literal Cornell scene has four coincident spheres): strict < keeps the
     lowest index (src/Renderer.cpp:67), also across geometry batches."""
