@@ -68,7 +68,10 @@ struct RenderParams {
     unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
     // sample split (SPLIT kernels): `split` waves per tile; wave 0 traces samples [0, split_head), wave f >= 1
     // samples [split_head + (f-1)*split_len, split_head + f*split_len)
-    unsigned n_tiles, split, split_head, split_len;
+    // Tiles [0, split_first) are NOT split (one wave traces all their samples and stores the pixel itself): a
+    // long launch splits only its last tiles, whose short waves fill the SIMDs that the last whole tiles leave
+    // idle one after another.  n_tiles counts the split tiles; their blocks follow the whole tiles' in the grid.
+    unsigned n_tiles, split, split_head, split_len, split_first;
     double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_head samples
     double* __restrict__ contrib;  // [tile][total_samples - split_head][3][64]: per-sample terms of waves 1..
 };
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     auto pixel_xy = [&](int& px, int& py) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        const unsigned tile = SPLIT ? blockIdx.x % P.n_tiles : blockIdx.x;
+        const unsigned tile = (SPLIT && blockIdx.x >= P.split_first)
+                                  ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles : blockIdx.x;
         const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
         px = tx * 8 + (l & 7);
         py = band_row(P, ty, l >> 3);
@@ -305,9 +309,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     D3 acc = d3(0, 0, 0);
 
     // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
-    const unsigned split_f = SPLIT ? blockIdx.x / P.n_tiles : 0u;
+    const bool whole = !SPLIT || blockIdx.x < P.split_first;  // this wave traces all samples of its tile
+    const unsigned split_f = whole ? 0u : (blockIdx.x - P.split_first) / P.n_tiles;
+    const unsigned split_tile = whole ? 0u : (blockIdx.x - P.split_first) % P.n_tiles;  // index into partial / contrib
     const unsigned n_first = (SPLIT && split_f != 0) ? P.split_head + (split_f - 1u) * P.split_len : 0u;
-    const unsigned n_end = SPLIT ? (split_f != 0 ? n_first + P.split_len : P.split_head) : P.total_samples;
+    const unsigned n_end = whole ? P.total_samples : (split_f != 0 ? n_first + P.split_len : P.split_head);
     unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
     int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
     const int sub_first = (int)(n_first / (unsigned)P.S);
@@ -382,8 +388,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     // no better (8.5 GB).  Only whole-line stores by one instruction would end that (entries written in
                     // fold order by the folding lanes, reordered by the finalize kernel): not built, the kernel is not
                     // bound by this traffic (~0.6 TB/s).
-                    const unsigned tile = blockIdx.x % P.n_tiles;
-                    double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)tile * (P.total_samples - P.split_head) * 64;
+                    double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)split_tile * (P.total_samples - P.split_head) * 64;
                     const unsigned s_rel = (n - pend) - P.split_head;  // n - pend: this entry's sample
                     cells[(size_t)s_rel * 64 + lane] = double4{fq_out[0 * 64 + rel], fq_out[1 * 64 + rel], fq_out[2 * 64 + rel], 0.0};
                 } else {
@@ -617,8 +622,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
             const D3 add = clamp01_d3(cal);
             if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
-                const unsigned tile = blockIdx.x % P.n_tiles;
-                double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)tile * (P.total_samples - P.split_head) * 64;
+                double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)split_tile * (P.total_samples - P.split_head) * 64;
                 cells[(size_t)(n - P.split_head) * 64 + lane] = double4{add.x, add.y, add.z, 0.0};
             } else if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
                 park[0 * 64 + lane] += add.x;
@@ -669,17 +673,15 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 
     if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
-    if constexpr (SPLIT) {
-        if (split_f == 0) {
-            double* dst = P.partial + (size_t)(blockIdx.x % P.n_tiles) * 192 + lane;
-            dst[0] = acc.x;
-            dst[64] = acc.y;
-            dst[128] = acc.z;
-        }
-    } else {
+    if (whole) {
         int px, py;
         pixel_xy(px, py);
         store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
+    } else if (split_f == 0) {
+        double* dst = P.partial + (size_t)split_tile * 192 + lane;
+        dst[0] = acc.x;
+        dst[64] = acc.y;
+        dst[128] = acc.z;
     }
     if (P.counters) {
         if constexpr (DEFER) {
@@ -702,11 +704,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 // (one per lane), independent of the adds.
 __global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P) {
     const int lane = threadIdx.x;
-    const unsigned tile = blockIdx.x;
-    const double* part = P.partial + (size_t)tile * 192 + lane;
+    const unsigned tile = P.split_first + blockIdx.x;  // blockIdx.x: index among the split tiles
+    const double* part = P.partial + (size_t)blockIdx.x * 192 + lane;
     D3 acc = d3(part[0], part[64], part[128]);
     const unsigned ns = P.total_samples - P.split_head;
-    const double4* cells = reinterpret_cast<const double4*>(P.contrib) + (size_t)tile * ns * 64 + lane;
+    const double4* cells = reinterpret_cast<const double4*>(P.contrib) + (size_t)blockIdx.x * ns * 64 + lane;
     unsigned m = 0;
     for (; m + 8 <= ns; m += 8) {
         double4 v[8];
@@ -1713,10 +1715,10 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
     } else if (variant == kVariantFastLds) {
         if (P.split > 1) {
             if (n < 8)
-                launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
+                launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
             else
-                launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
-            split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
+                launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
+            split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
         } else if (n < 8) {  // no full chunk of 8: the instantiation without the chunk loop
             launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         } else {
@@ -1736,8 +1738,8 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, uns
                 <<<grid, 64, lds, stream>>>(P);
     } else if (variant == kVariantGlobalDefer && n < 256) {
         if (P.split > 1) {
-            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, grid * P.split, stream);
-            split_finalize_kernel<<<grid, 64, 0, stream>>>(P);
+            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
+            split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
         } else {
             launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
         }
@@ -1929,32 +1931,51 @@ int release_scratch(int device) {
     return RTM_OK;
 }
 
-// Sample split of the default kernel.  A launch with fewer tiles than about six rounds of resident waves
-// (256 CUs x 4 SIMDs x 4 waves on MI355X) ends with SIMDs idling while the costliest tiles finish:
-// measured max/mean per-tile cost on the Cornell box is ~1.27 (profiles/r1/strip_balance.txt).  Such a
-// launch is cut finer: the result is the GRANULARITY g — small waves trace 1/g of a pixel's samples, and
-// (render_device) wave 0 of a tile takes half of them when g >= 4.  1/16 is the measured sweet spot for
-// one-eighth to one-half of a 1080p frame (profiles/r1/band_split_sweep_final.json); short sample counts
-// and the term buffer (2048 B per tile-sample that is not wave 0's, at most 24 GiB) cap it.
-static unsigned choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
+// Sample split of the default kernel.  A launch ends with SIMDs falling idle one after another while the last
+// tiles finish (a tile is ~22 ms of one wave on a full chip, and max/mean per-tile cost on the Cornell box is
+// ~1.27, profiles/r1/strip_balance.txt): 4-5 % of the 7.9-round headline launch, a quarter of a one-round launch
+// (one GPU's share of eight).  The LAST tiles of every launch are therefore cut finer — wave 0 of such a tile
+// takes half of its samples, small waves 1/g of them each (g = 16: profiles/r1/band_split_sweep_final.json) —
+// and, coming last in the grid, fill that ramp.  Only the last ones: a small wave pays the kernel's prologue and
+// its own ragged end (lanes waiting for the slowest of 64) once per 32 samples instead of once per 1024, so
+// splitting EVERY tile of a launch of 2-4 rounds, round 1's rule, cost 8 % against splitting 1 536 of them
+// (profiles/r2/tail_split.txt).  Launches of up to 1 536 tiles are split whole, as before.
+struct SplitPlan {
+    unsigned g;      // granularity: small waves trace 1/g of a pixel's samples (1: no split)
+    unsigned tiles;  // how many of the launch's LAST tiles are split
+};
+static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
     static const long env = [] {
-        const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, g = that granularity
+        const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, g = every tile with that granularity
         return e ? std::strtol(e, nullptr, 10) : 0L;
+    }();
+    static const long env_tail = [] {
+        const char* e = std::getenv("RTM_DEBUG_TAIL");  // tuning knob: number of split tiles (0 = none)
+        return e ? std::strtol(e, nullptr, 10) : -1L;
     }();
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const unsigned slots = (unsigned)cus * 16u;
-    auto fits = [&](unsigned g) {
+    auto fits = [&](unsigned g, unsigned tiles) {
         if (g < 2 || total_samples % g != 0 || total_samples / g < 8) return false;
         const unsigned head = g >= 4 ? total_samples / 2 : total_samples / g;
         const double per_tile = (double)(total_samples - head) * 2048.0;  // 64 lanes x 32-byte cells per deferred sample
-        return (double)n_tiles * per_tile <= 24.0 * 1024 * 1024 * 1024 && per_tile < 4.0e9;
+        return (double)tiles * per_tile <= 24.0 * 1024 * 1024 * 1024 && per_tile < 4.0e9;
     };
-    if (env > 0) return (env > 1 && fits((unsigned)env)) ? (unsigned)env : 1u;
-    if (!forced && (unsigned long long)n_tiles >= 6ull * slots) return 1u;
-    unsigned g = 1;
-    while (g < 16u && fits(g * 2)) g *= 2;
-    return g;
+    auto finest = [&](unsigned tiles) {
+        unsigned g = 1;
+        while (g < 16u && fits(g * 2, tiles)) g *= 2;
+        return g;
+    };
+    if (env > 0) return (env > 1 && fits((unsigned)env, n_tiles)) ? SplitPlan{(unsigned)env, n_tiles} : SplitPlan{1u, 0u};
+    unsigned tail = forced ? n_tiles : env_tail >= 0 ? (unsigned)env_tail : 3u * slots / 8u;
+    if (tail > n_tiles) tail = n_tiles;
+    unsigned g = tail ? finest(tail) : 1u;
+    while (g <= 1u && tail > 64u && !forced) {  // many samples per pixel: a shorter tail whose terms fit
+        tail /= 2u;
+        g = finest(tail);
+    }
+    return g > 1 ? SplitPlan{g, tail} : SplitPlan{1u, 0u};
 }
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): nearest / shade launches until the compacted active
@@ -2189,8 +2210,11 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     // the sample split rides on the packed-record kernels (explicit variant 2 never splits)
     if (n < 256 && (opt->variant == kVariantAuto || force_split) &&
         (variant == kVariantFastLds || variant == kVariantGlobalDefer)) {
-        P.split = choose_split(grid, P.total_samples, opt->device, force_split);
+        const SplitPlan plan = choose_split(grid, P.total_samples, opt->device, force_split);
+        P.split = plan.g;
         if (P.split > 1) {
+            P.n_tiles = plan.tiles;
+            P.split_first = grid - plan.tiles;
             // choose_split gives the granularity (1/f of a pixel's samples per small wave).  Wave 0 takes half
             // of the samples when f >= 4: its terms never leave the chip, which halves the term traffic
             // (7/8 -> 1/2 of the samples at f = 8), and it starts in the first round, so the small waves
@@ -2198,7 +2222,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
             P.split_len = P.total_samples / P.split;
             P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
-            const size_t part = (size_t)grid * 192, terms = (size_t)grid * (P.total_samples - P.split_head) * 256;
+            const size_t part = (size_t)P.n_tiles * 192, terms = (size_t)P.n_tiles * (P.total_samples - P.split_head) * 256;
             rc = scratch_acquire(ctx, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
             if (rc != RTM_OK) return rc;
             P.partial = split_ws;
@@ -2212,7 +2236,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                        (variant == kVariantFastLds || variant == kVariantGlobalDefer);
     if (needs_pool(P)) {
         const size_t rec_bytes = (n <= 256) ? 1 : 4;
-        P.pool_slots = packl ? grid * P.split * 64u : 65536u;
+        P.pool_slots = packl ? (P.split_first + P.n_tiles * P.split) * 64u : 65536u;
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
         rc = scratch_acquire(ctx, kScratchPool, pool_bytes + 64, (void**)&pool);
         if (rc != RTM_OK) return rc;

@@ -973,7 +973,7 @@ def test_config4_band_parts_vs_oracle(rtm, oracle):
         part, ps = r.render_rows_device(0, H, want=("f64",), band=(8, rank))
         rows = band_row_index(0, H, 8, rank)
         assert part["f64"].shape == (len(rows), W, 3)
-        # (no sample split here: 16 320 tiles x 2 048 deferred samples of terms would be 51 GB, over the 24 GB budget)
+        # (only the last 1 536 of the part's 16 320 tiles are sample-split: 6.4 GB of terms; all of them would be 51 GB)
         frame[rows] = part["f64"].cpu().numpy()
         for k in total:
             total[k] += ps[k]
@@ -987,8 +987,8 @@ def test_config4_band_parts_vs_oracle(rtm, oracle):
     assert total["samples"] == W * H * S * SS * SS
     assert 3 * total["bounces"] <= total["draws"] <= total["casts"] + 2 * total["bounces"]
     assert np.isfinite(frame).all() and frame.min() >= 0.0
-    whole, ws = r.render_rows_device(want=("f64",))  # one launch, no split: 3.4e10 samples
-    assert ws["split"] == 1 and {k: ws[k] for k in total} == total
+    whole, ws = r.render_rows_device(want=("f64",))  # one launch of 129 600 tiles: 3.4e10 samples
+    assert {k: ws[k] for k in total} == total
     assert _bits_equal(whole["f64"].cpu().numpy(), frame)
 
 
