@@ -1253,7 +1253,7 @@ namespace rtm {
 
 static size_t scene_aux_doubles(size_t n) {
     const size_t n_pad = (n + 7) & ~(size_t)7;
-    return n_pad * 3 + 4;
+    return n_pad * 5 + 4;  // bounds[4], w'[n_pad], float list in sphere pairs (n_pad x 16 B), float list per sphere (same)
 }
 // bounds / w' / float list of the large-scene rejection tests, on `stream`
 static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream_t stream) {
@@ -1264,7 +1264,7 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
         wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>((const double4*)geom, (int)n,
                                                                       reinterpret_cast<long long*>(aux + 2));
         wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256, 0, stream>>>((const double4*)geom, (int)n, n_pad, aux + 4,
-                                                                    reinterpret_cast<unsigned long long*>(aux), g32);
+                                                                    reinterpret_cast<unsigned long long*>(aux), g32, g32 + n_pad);
     }
     RTM_HIP_CHECK(hipGetLastError());
     return RTM_OK;
@@ -1278,6 +1278,7 @@ static SceneView scene_view(const double* geom, const double* mat, const double*
         v.bounds = aux;
         v.wprime = aux + 4;
         v.geom32 = reinterpret_cast<const float4*>(aux + 4 + n_pad);
+        v.geom32s = v.geom32 + n_pad;
     }
     return v;
 }
@@ -2074,11 +2075,18 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
             while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * parts * 2 <= (1ull << 20) &&
                    P.scene.n / (parts * 2) >= 2048)
                 parts *= 2;
+        static const bool x1 = [] {
+            const char* e = std::getenv("RTM_DEBUG_WF_X2");  // A/B: "1" selects the two-rays-per-lane rejection kernel
+            return !(e && e[0] == '1');
+        }();
+        const unsigned g2 = x1 ? g : (na + 511) / 512;  // blocks of the two-rays-per-lane kernel
         S.parts = parts;
-        S.part_blocks = g;
+        S.part_blocks = scalar_scene == 3 ? g2 : g;
         for (int k = 0; k < batch; ++k, ++trip) {
             RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-            if (scalar_scene == 3)
+            if (scalar_scene == 3 && !x1)
+                wf_nearest_f32x2_kernel<MathFast, 256, 8><<<g2 * (unsigned)parts, 256, 2 * 256 * kWfCandCapX2 * sizeof(unsigned), stream>>>(P, S, cur);
+            else if (scalar_scene == 3)
                 wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
             else if (scalar_scene == 2)
                 wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(P, S, cur);
@@ -2606,7 +2614,7 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
 // stream, 2: scalar stream + rejection test.  Host buffers; out_id/out_t per ray.
 int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                      int32_t* out_id, double* out_t) {
-    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 3 || n_rays > 0x7FFFFFFFull)
+    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 4 || n_rays > 0x7FFFFFFFull)
         return RTM_ERR_INVALID_ARGUMENT;
     int device = 0;
     RTM_HIP_CHECK(hipGetDevice(&device));
@@ -2621,7 +2629,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     const size_t N = n_rays;
     S.npix = (unsigned)N;
     const int n_pad = ((int)n + 7) & ~7;
-    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 3 + 4) * 8 + 256;
+    const size_t bytes = N * (24 + 24 + 8 + 4 + 4) + 64 + ((size_t)n_pad * 5 + 4) * 8 + 256;
     DevMem ws_mem;
     if ((rc = ws_mem.alloc(bytes)) != RTM_OK) return rc;
     unsigned char* ws = ws_mem.as<unsigned char>();
@@ -2637,7 +2645,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     S.hit_id = (int*)take(N * 4);
     S.active[0] = (unsigned*)take(N * 4);
     S.n_active = (unsigned*)take(16);
-    double* aux = (double*)take(((size_t)n_pad * 3 + 4) * 8);
+    double* aux = (double*)take(((size_t)n_pad * 5 + 4) * 8);
     std::vector<double> soa(N * 3);
     std::vector<unsigned> ident(N);
     for (size_t i = 0; i < N; ++i) {
@@ -2657,11 +2665,14 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
         float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
         wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, reinterpret_cast<long long*>(aux + 2));
         wf_scene_aux_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, n_pad, aux + 4,
-                                                          reinterpret_cast<unsigned long long*>(aux), g32);
+                                                          reinterpret_cast<unsigned long long*>(aux), g32, g32 + n_pad);
         P.scene.bounds = aux;
         P.scene.wprime = aux + 4;
         P.scene.geom32 = g32;
-        if (kind == 3)
+        P.scene.geom32s = g32 + n_pad;
+        if (kind == 4)  // two rays per lane (A/B twin, RTM_DEBUG_WF_X2=1)
+            wf_nearest_f32x2_kernel<MathFast, 256, 8><<<(unsigned)((N + 511) / 512), 256, 2 * 256 * kWfCandCapX2 * sizeof(unsigned)>>>(P, S, 0);
+        else if (kind == 3)  // the default: two spheres per packed instruction
             wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 256 * kWfCandCap * sizeof(unsigned)>>>(P, S, 0);
         else
             wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);

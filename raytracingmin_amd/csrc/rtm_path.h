@@ -423,6 +423,7 @@ struct SceneView {
     const double* __restrict__ wprime = nullptr;
     const double* __restrict__ bounds = nullptr;
     const float4* __restrict__ geom32 = nullptr;  // (float)cx, cy, cz, (float)w' (padded like wprime)
+    const float4* __restrict__ geom32s = nullptr;  // the same numbers, one float4 (cx, cy, cz, w') per sphere
     // RTM_MODE_HOST_TRIG: 4 bits per possible r1 (2^23 of them): the differences, in units of the last
     // place, between the host libm's sin/cos and the device's (rtm_kernels.hip, ensure_trig_fix)
     const uint32_t* __restrict__ trig_fix = nullptr;

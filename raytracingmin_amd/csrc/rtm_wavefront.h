@@ -50,6 +50,7 @@ struct WfState {
     double* part_t;
     int* part_id;
 };
+constexpr int kWfCandCapX2 = 12;             // the same per RAY of wf_nearest_f32x2_kernel (two rays per lane: 24 KB per block)
 constexpr int kWfCandCap = 16;               // candidate slots per lane of wf_nearest_f32_kernel (LDS: 4 B x BLOCK each)
 constexpr unsigned kWfPartSlots = 1u << 19;  // the split is used only while the active list is this short
 constexpr int kWfMaxParts = 8;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void wf_scene_scale_kernel(const double4* __re
 
 __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __restrict__ geom, const int n, const int n_pad,
                                                            double* __restrict__ wprime, unsigned long long* __restrict__ bounds,
-                                                           float4* __restrict__ geom32) {
+                                                           float4* __restrict__ geom32, float4* __restrict__ geom32s) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     float* q = geom32 ? reinterpret_cast<float*>(geom32) + (size_t)(i >> 1) * 8 + (i & 1) : nullptr;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __rest
             q[0] = q[2] = q[4] = 0.f;
             q[6] = -HUGE_VALF;
         }
+        if (geom32s) geom32s[i] = float4{0.f, 0.f, 0.f, -HUGE_VALF};
         return;
     }
     const long long* acc = reinterpret_cast<const long long*>(bounds + 2);
@@ -216,6 +218,8 @@ __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __rest
         q[4] = outlier ? 0.f : (float)g.z;
         q[6] = outlier ? HUGE_VALF : (float)(g.w - cc);
     }
+    if (geom32s)
+        geom32s[i] = outlier ? float4{0.f, 0.f, 0.f, HUGE_VALF} : float4{(float)g.x, (float)g.y, (float)g.z, (float)(g.w - cc)};
     if (outlier) return;
     // max over non-negative doubles == max over their bit patterns; NaN / negative values stay out
     if (cc >= 0.0) atomicMax(bounds + 0, (unsigned long long)__double_as_longlong(cc));
@@ -503,6 +507,233 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         } else {
             S.part_id[(size_t)(part - 1u) * S.part_slots + i] = id;
             S.part_t[(size_t)(part - 1u) * S.part_slots + i] = dis;
+        }
+    }
+}
+
+// ---- two rays per lane -------------------------------------------------------------------------------------------
+// The packed instructions of wf_nearest_f32_kernel carry two SPHERES for one ray, so every sphere operand is an SGPR
+// pair and the addend w' has to be moved into a vector register first (a VOP3P instruction reads ONE scalar operand):
+// 8 instructions per sphere pair, 38 per chunk of 8 with the maximum and the compare.  Here they carry two RAYS for
+// one sphere: the sphere's (cx, cy) and (cz, w') are two SGPR pairs, each instruction broadcasts one HALF of one pair to
+// both rays through op_sel, and "cz * ez + w'" reads both of its scalar operands from the SAME pair — 7 instructions
+// per sphere and ray pair, no moves: 66 per chunk of 8 spheres x 128 rays instead of 76.  Same arithmetic per (ray,
+// sphere) as before up to the order of the three products of c.e (the margin bounds every partial sum by the same
+// quantity), same candidate lists, same exact settlement.
+typedef float wf_f2 __attribute__((ext_vector_type(2)));
+// d = s.x * v + c / d = s.y * v + c / d = s.x * v + s.y / d = s.x * v   (s: a sphere's SGPR pair, v and c: the two rays)
+__device__ __forceinline__ wf_f2 pk_fma_sx(unsigned long long s, wf_f2 v, wf_f2 c) {
+    wf_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(s), "v"(v), "v"(c));
+    return d;
+}
+__device__ __forceinline__ wf_f2 pk_fma_sy(unsigned long long s, wf_f2 v, wf_f2 c) {
+    wf_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(s), "v"(v), "v"(c));
+    return d;
+}
+__device__ __forceinline__ wf_f2 pk_fma_sx_sy(unsigned long long s, wf_f2 v) {
+    wf_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "s"(s), "v"(v));
+    return d;
+}
+__device__ __forceinline__ wf_f2 pk_mul_sx(unsigned long long s, wf_f2 v) {
+    wf_f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(s), "v"(v));
+    return d;
+}
+
+template <class M, int BLOCK, int K>
+__global__ __launch_bounds__(BLOCK) void wf_nearest_f32x2_kernel(const RenderParams P, const WfState S, const int cur) {
+    static_assert(K == 8, "two 64-byte scalar loads per chunk");
+    const unsigned na = S.n_active[cur];
+    const int parts = S.parts > 1 ? S.parts : 1;
+    const unsigned part = parts > 1 ? blockIdx.x / S.part_blocks : 0u;       // wave-uniform
+    const unsigned ray_block = parts > 1 ? blockIdx.x % S.part_blocks : blockIdx.x;
+    if (ray_block * (unsigned)(2 * BLOCK) >= na) return;
+    const unsigned N = S.npix;
+    const int n = P.scene.n;
+    typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+    typedef const __attribute__((address_space(4))) unsigned long long* ConstU64Ptr;
+    ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
+    const double R2 = bnd[0], r2max = bnd[1];
+    const double R = __builtin_sqrt(R2) * (1.0 + 0x1p-40);
+
+    // ray h of this lane: slot i_h of the active list
+    struct Ray {  // (origin and direction are re-read from the ray arrays where the exact test needs them)
+        double dis;
+        int id, cnt;
+        unsigned i, p;
+        bool live;
+    } ray[2];
+    float thr[2], fd[2][3], fe[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        Ray& r = ray[h];
+        r.i = ray_block * (unsigned)(2 * BLOCK) + (unsigned)h * BLOCK + threadIdx.x;
+        r.live = r.i < na;
+        r.p = S.active[cur][r.live ? r.i : na - 1];
+        r.dis = DBL_MAX;
+        r.id = -1;
+        r.cnt = 0;
+        const D3 org = d3(S.org[r.p], S.org[N + r.p], S.org[2 * N + r.p]);
+        const D3 dir = d3(S.dir[r.p], S.dir[N + r.p], S.dir[2 * N + r.p]);
+        // the per-ray constants of the rejection test: exactly wf_nearest_f32_kernel's
+        const double od = __builtin_fma(org.z, dir.z, __builtin_fma(org.y, dir.y, org.x * dir.x));
+        const double oo = __builtin_fma(org.z, org.z, __builtin_fma(org.y, org.y, org.x * org.x));
+        const double dd = __builtin_fma(dir.z, dir.z, __builtin_fma(dir.y, dir.y, dir.x * dir.x));
+        const double od2 = od + od;
+        const D3 e = d3(__builtin_fma(-od2, dir.x, org.x + org.x), __builtin_fma(-od2, dir.y, org.y + org.y),
+                        __builtin_fma(-od2, dir.z, org.z + org.z));
+        const double kq = __builtin_fma(od, od, -oo);
+        const double e1 = __builtin_fabs(e.x) + __builtin_fabs(e.y) + __builtin_fabs(e.z);
+        const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
+        const double mag = R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max;
+        const double m32 = 0x1p-24 * (12.0 * (R2 * dd) + 7.0 * (R * e1) + 6.0 * (R2 + r2max)) + 0x1p-110 * (1.0 + dd + e1 + R2);
+        float t = -HUGE_VALF;
+        if (mag < 0x1p100) {
+            const double thr64 = -((m32 + m64 + 0x1p-23 * __builtin_fabs(kq)) * (1.0 + 0x1p-20)) - kq;
+            t = (float)thr64;
+            if ((double)t > thr64) t = __uint_as_float(t > 0.f ? __float_as_uint(t) - 1u :
+                                                       t < 0.f ? __float_as_uint(t) + 1u : 0x80000001u);  // next float below
+        }
+        thr[h] = t;
+        fd[h][0] = (float)dir.x; fd[h][1] = (float)dir.y; fd[h][2] = (float)dir.z;
+        fe[h][0] = (float)e.x; fe[h][1] = (float)e.y; fe[h][2] = (float)e.z;
+    }
+    const wf_f2 dx2 = wf_f2{fd[0][0], fd[1][0]}, dy2 = wf_f2{fd[0][1], fd[1][1]}, dz2 = wf_f2{fd[0][2], fd[1][2]};
+    const wf_f2 ex2 = wf_f2{fe[0][0], fe[1][0]}, ey2 = wf_f2{fe[0][1], fe[1][1]}, ez2 = wf_f2{fe[0][2], fe[1][2]};
+
+    // per-ray candidate lists in LDS, [ray half][slot][thread]
+    extern __shared__ unsigned cand[];
+    auto drain = [&](int h) {
+        Ray& r = ray[h];
+        if (__builtin_amdgcn_ballot_w64(r.cnt > 0) == 0) return;
+        unsigned* list = cand + h * (kWfCandCapX2 * BLOCK);
+        unsigned pp = r.p;
+        asm volatile("" : "+v"(pp));  // the loads stay HERE: hoisted out of the sweep they would pin 24 registers
+        const D3 org = d3(S.org[pp], S.org[N + pp], S.org[2 * N + pp]);
+        const D3 dir = d3(S.dir[pp], S.dir[N + pp], S.dir[2 * N + pp]);
+        for (int e = 0; __builtin_amdgcn_ballot_w64(e < r.cnt) != 0; ++e) {
+            if (e < r.cnt) {
+                const int jj = (int)list[e * BLOCK + threadIdx.x];
+                const double4 g = P.scene.geom[jj];
+                const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
+                const double b = dot(p_o, dir);                            // :199
+                const double D4 = b * b - dot(p_o, p_o) + g.w;                    // :200
+                const double sq = M::sqrt64(D4);                                  // :205 (D4 < 0: NaN, nothing is accepted)
+                const double t1 = b - sq, t2 = b + sq;
+                const double t = (t1 > 0.001) ? t1 : t2;
+                const bool accept = (t < r.dis) && !(t < (double)1e-5f);
+                r.dis = accept ? t : r.dis;
+                r.id = accept ? jj : r.id;
+            }
+        }
+        r.cnt = 0;
+    };
+    struct Chunk {
+        unsigned long long xy[K], zw[K];  // per sphere: (cx, cy) and (cz, w') as SGPR pairs
+    };
+    auto load32 = [&](int j, Chunk& c) {
+        ConstU64Ptr q = (ConstU64Ptr)(unsigned long long)(reinterpret_cast<const unsigned long long*>(P.scene.geom32s) + (size_t)j * 2);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            c.xy[k] = q[2 * k];
+            c.zw[k] = q[2 * k + 1];
+        }
+    };
+    auto test = [&](const Chunk& c, int j) {
+        wf_f2 tq[K];
+        // two spheres at a time, stage by stage: four independent chains, so that no instruction needs the result of the
+        // one before it (a dependent packed instruction costs a wait state)
+#pragma unroll
+        for (int k = 0; k < K; k += 2) {
+            wf_f2 u0 = pk_mul_sx(c.xy[k], dx2);
+            wf_f2 v0 = pk_fma_sx_sy(c.zw[k], ez2);
+            wf_f2 u1 = pk_mul_sx(c.xy[k + 1], dx2);
+            wf_f2 v1 = pk_fma_sx_sy(c.zw[k + 1], ez2);
+            u0 = pk_fma_sy(c.xy[k], dy2, u0);
+            v0 = pk_fma_sx(c.xy[k], ex2, v0);
+            u1 = pk_fma_sy(c.xy[k + 1], dy2, u1);
+            v1 = pk_fma_sx(c.xy[k + 1], ex2, v1);
+            u0 = pk_fma_sx(c.zw[k], dz2, u0);
+            v0 = pk_fma_sy(c.xy[k], ey2, v0);
+            u1 = pk_fma_sx(c.zw[k + 1], dz2, u1);
+            v1 = pk_fma_sy(c.xy[k + 1], ey2, v1);
+            tq[k] = __builtin_elementwise_fma(u0, u0, v0);
+            tq[k + 1] = __builtin_elementwise_fma(u1, u1, v1);
+        }
+        float top0 = tq[0].x, top1 = tq[0].y;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {  // v_max_f32 / v_max3_f32 skip NaN operands
+            top0 = __builtin_fmaxf(top0, tq[k].x);
+            top1 = __builtin_fmaxf(top1, tq[k].y);
+        }
+        const unsigned long long any0 = __builtin_amdgcn_ballot_w64(top0 >= thr[0]);
+        const unsigned long long any1 = __builtin_amdgcn_ballot_w64(top1 >= thr[1]);
+        if ((any0 | any1) == 0ull) return;
+        // rare: a sphere some ray could not reject goes to that ray's list (index order: strict < keeps the lowest on
+        // ties); only the half that has such a ray is looked through
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((h ? any1 : any0) == 0ull) continue;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float t = h ? tq[k].y : tq[k].x;
+                const bool pass = !(t < thr[h]);
+                if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+                if (pass) {
+                    cand[h * (kWfCandCapX2 * BLOCK) + ray[h].cnt * BLOCK + threadIdx.x] = (unsigned)(j + k);
+                    ++ray[h].cnt;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(ray[h].cnt > kWfCandCapX2 - K) != 0) drain(h);  // the next chunk might not fit
+        }
+    };
+
+    // this block's range of the sphere list: all of it, or part `part` of `parts` (cut on chunk-pair boundaries)
+    const int n_pairs_all = n / (2 * K);
+    const int pairs_per = (n_pairs_all + parts - 1) / parts;
+    const int j_begin = (int)part * pairs_per * 2 * K;
+    const int j_end_full = ((int)part + 1 == parts) ? n_pairs_all * 2 * K
+                                                   : (((int)part + 1) * pairs_per < n_pairs_all ? ((int)part + 1) * pairs_per
+                                                                                              : n_pairs_all) * 2 * K;
+    Chunk a, b;
+    if (j_begin < j_end_full) load32(j_begin, a);
+    for (int j = j_begin; j < j_end_full; j += 2 * K) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        load32(j + K, b);
+        __builtin_amdgcn_sched_barrier(0);
+        test(a, j);
+        const int jn = (j + 2 * K < j_end_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        load32(jn, a);
+        __builtin_amdgcn_sched_barrier(0);
+        test(b, j + K);
+    }
+    drain(0);
+    drain(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        Ray& r = ray[h];
+        if ((int)part + 1 == parts && n_pairs_all * 2 * K < n) {  // the spheres after the last full chunk pair: the last part's
+            const D3 org = d3(S.org[r.p], S.org[N + r.p], S.org[2 * N + r.p]);
+            const D3 dir = d3(S.dir[r.p], S.dir[N + r.p], S.dir[2 * N + r.p]);
+            for (int j = n_pairs_all * 2 * K; j < n; ++j) {
+                double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
+                sphere_chunk_g<M, 1, true>(g1, j, org, dir, r.dis, r.id);
+            }
+        }
+        if (r.live) {
+            if (part == 0u) {
+                S.hit_id[r.p] = r.id;
+                S.hit_t[r.p] = r.dis;
+            } else {
+                S.part_id[(size_t)(part - 1u) * S.part_slots + r.i] = r.id;
+                S.part_t[(size_t)(part - 1u) * S.part_slots + r.i] = r.dis;
+            }
         }
     }
 }

@@ -194,7 +194,7 @@ def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
         rays_d.append(np.array(d, dtype=np.float64))
     rays_o, rays_d = np.array(rays_o), np.array(rays_d)
     ref_id, ref_t = _wf_nearest(rtm, 1, arr, n, rays_o, rays_d)
-    for kind in (0, 2, 3):
+    for kind in (0, 2, 3, 4):  # 3: two spheres per packed instruction (default), 4: two rays (A/B twin)
         ids, t = _wf_nearest(rtm, kind, arr, n, rays_o, rays_d)
         assert np.array_equal(ids, ref_id), kind
         assert np.array_equal(t.view(np.uint64), ref_t.view(np.uint64)), kind
@@ -211,7 +211,7 @@ def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
             big[i].radius = min(float(r[i]) * scale, 3.0e38)
         o_big = rays_o[:4000] * scale
         want_id, want_t = _wf_nearest(rtm, 1, big, n, o_big, rays_d[:4000])
-        for kind in (2, 3):
+        for kind in (2, 3, 4):
             ids, t = _wf_nearest(rtm, kind, big, n, o_big, rays_d[:4000])
             assert np.array_equal(ids, want_id) and np.array_equal(t.view(np.uint64), want_t.view(np.uint64)), (scale, kind)
     oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
