@@ -352,7 +352,8 @@ def main():
             traffic = tj["bytes_per_launch"]  # PMC bytes of a committed rocprofv3 --pmc pass of this command
             traffic_src = {"measured_in_run": False, "file": "profiles/latest_traffic.json",
                            "profile": tj.get("source", "profiles/r1/default_pmc_summary.json"),
-                           "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes"}
+                           "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes",
+                           "note": tj.get("note")}
         resolved = rtm.lib().rtm_variant_name(stats["variant"]).decode()  # what the library ran (rtm_stats.variant)
         line = {
             "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp" if args.workload == "c3" else
