@@ -930,6 +930,31 @@ def test_headline_config_strip_vs_oracle(rtm, oracle):
     assert np.array_equal(dt["f64"].cpu().numpy().view(np.uint64), img.view(np.uint64)) and st["casts"] == stats["casts"]
 
 
+def test_mixed_whole_and_split_launch_vs_oracle(rtm, oracle):
+    """A launch of more than 1 536 tiles keeps its first tiles whole and sample-splits the last 1 536 behind them in the
+    same grid (csrc/rtm_kernels.hip choose_split; src/Renderer.cpp:240-248 fixes only the ORDER of the additions).
+    400x328 = 2 050 tiles: 514 whole + 1 536 split, every bit and counter against the oracle, with a row range and an
+    interleaved band part on top (their tile numbering differs from the full frame's)."""
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    data = rtm.LoadData(scene).data
+    W, H = 400, 328
+    data.width, data.height, data.samples, data.superSamples = W, H, 8, 2
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=77)
+    out, stats = r.render_rows_device(want=("f64",))
+    assert stats["split"] > 1
+    st, arr, n = oracle.load_scene(scene, width=W, height=H, samples=8, super_samples=2)
+    ref, cnt = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=8, seed=77, height=H))
+    img = out["f64"].cpu().numpy()
+    assert np.array_equal(img.view(np.uint64), ref.view(np.uint64))
+    assert {k: stats[k] for k in ("samples", "casts", "bounces", "draws")} == {k: cnt[k] for k in ("samples", "casts", "bounces", "draws")}
+    part, _ = r.render_rows_device(16, 312, want=("f64",))  # 1 850 tiles: 314 whole + 1 536 split
+    assert np.array_equal(part["f64"].cpu().numpy().view(np.uint64), ref[16:312].view(np.uint64))
+    from raytracingmin_amd.distributed import band_row_index
+    band, _ = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=77).render_rows_device(0, H, want=("f64",), band=(1, 0))
+    ref_u, _ = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=-1, seed=77, height=H))
+    assert np.array_equal(band["f64"].cpu().numpy().view(np.uint64), ref_u[band_row_index(0, H, 1, 0)].view(np.uint64))
+
+
 def _bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
 
