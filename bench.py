@@ -162,7 +162,7 @@ def other_configs(rtm, cfg, device, host_trig):
         "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
         "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
         "note": "a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the chip "
-                "(DESIGN.md §4); the full 1080p frame runs at 20.6 Msamples/s (profiles/r1/c5_full_frame_bench.json)"}
+                "(DESIGN.md §4); the full 1080p frame runs at 21.9 Msamples/s (profiles/r2/c5_full_frame_bench.json)"}
     return out
 
 
