@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     PathCounters pc = {0, 0, 0};
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
     if constexpr (PACKL) {
-        if (P.pool) stack.slot = (int)(blockIdx.x * 64u + (unsigned)lane);  // one pooled stack per lane, no allocator
+        if (P.pool) stack.slot = (int)((blockIdx.x * 64u + (unsigned)lane) * 2u);  // two pooled stacks per lane, no allocator
     }
     D3 acc = d3(0, 0, 0);
 
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         }
         // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
         for (;;) {
-            const unsigned pend = fq_pend[lane];
+            const unsigned pend = fq_pend[lane] & 0xFFu;  // (PACKL: bit 8 = "a deep entry of this lane may be waiting")
             const unsigned oldest = (unsigned)(fq_fifo[lane] >> (8u * ((pend ? pend : 1u) - 1u))) & 0xFFu;
             const unsigned rel = (oldest - fq_head) & (kFoldRing - 1);
             const bool mine = pend != 0u && rel < m;
@@ -396,7 +396,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     park[1 * 64 + lane] += fq_out[1 * 64 + rel];
                     park[2 * 64 + lane] += fq_out[2 * 64 + rel];
                 }
-                fq_pend[lane] = pend - 1u;
+                // (the last of the lane's entries: the deep flag goes too; otherwise it stays)
+                fq_pend[lane] = pend == 1u ? 0u : (fq_pend[lane] - 1u);
             }
         }
         fq_head = (fq_head + m) & (kFoldRing - 1);
@@ -550,10 +551,24 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     } else {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
                     }
-                    const unsigned pend = fq_pend[lane] + 1u;
+                    const unsigned pend_word = fq_pend[lane];  // count, and (PACKL) bit 8: a deep entry may be waiting
+                    const unsigned pend = (pend_word & 0xFFu) + 1u;
                     fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
-                    fq_pend[lane] = pend;
-                    fifo_full = pend >= 8u || (PACKL && depth > 16);  // pooled levels must be folded before reuse
+                    fifo_full = pend >= 8u;
+                    const bool deep_now = PACKL && depth > 16;
+                    fq_pend[lane] = pend | (pend_word & 0x100u) | (deep_now ? 0x100u : 0u);
+                    if constexpr (PACKL) {
+                        // Levels from 16 up sit in the lane's pooled stack and are read when the entry is folded, so the
+                        // lane's next path must not write there before.  The lane has TWO pooled stacks and changes over
+                        // whenever it queues such a path; only if the other one may still be waiting in the queue (a second
+                        // deep path before the lane's entries have all been folded: rare squared) is a pass forced.  Forcing
+                        // one for every deep path (P(depth > 16) = 1.5 % of the paths: every fifth trip of a wave) ran the
+                        // fold half empty that often: +4 % on the 512x512 unlimited-depth frame.
+                        if (deep_now) {
+                            fifo_full = fifo_full || (pend_word & 0x100u) != 0u;
+                            stack.slot ^= 1;
+                        }
+                    }
                 }
                 if constexpr (PACKL) {
                     if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
@@ -2244,7 +2259,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                        (variant == kVariantFastLds || variant == kVariantGlobalDefer);
     if (needs_pool(P)) {
         const size_t rec_bytes = (n <= 256) ? 1 : 4;
-        P.pool_slots = packl ? (P.split_first + P.n_tiles * P.split) * 64u : 65536u;
+        P.pool_slots = packl ? (P.split_first + P.n_tiles * P.split) * 128u : 65536u;  // two per lane
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
         rc = scratch_acquire(ctx, kScratchPool, pool_bytes + 64, (void**)&pool);
         if (rc != RTM_OK) return rc;
