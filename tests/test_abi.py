@@ -115,3 +115,31 @@ def test_graft_entry_build_runs():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_headers_compile_as_c99_and_link(tmp_path):
+    """include/rtm.h and include/rtm_debug.h are a C boundary: a strict C99 translation unit that includes both
+    compiles without a warning, links against librtm_hip.so and can call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text(
+        '#include "rtm.h"\n#include "rtm_debug.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        '    printf("%d %d %d %d\\n", (int)sizeof(rtm_settings), (int)sizeof(rtm_sphere), (int)sizeof(rtm_object), (int)sizeof(rtm_options));\n'
+        "    if (rtm_abi_version() != RTM_ABI_VERSION) return 1;\n"
+        "    if (!rtm_strerror(RTM_ERR_INVALID_ARGUMENT) || rtm_num_variants() < 15) return 2;\n"
+        "    return rtm_render(0, 0, 0, 0, 0, 0, 0, 0) == RTM_ERR_INVALID_ARGUMENT ? 0 : 3;\n"
+        "}\n")
+    exe = tmp_path / "hdr"
+    libdir = os.path.join(root, "raytracingmin_amd")
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                         str(src), "-o", str(exe), "-L", libdir, "-lrtm_hip", "-Wl,-rpath," + libdir],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert run.stdout.split() == ["96", "80", "136", "40"]
