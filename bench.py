@@ -166,6 +166,42 @@ def other_configs(rtm, cfg, device, host_trig):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves — BEFORE this
+    process imports torch or touches a GPU — through torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port), pass rank 0's single JSON line through on stdout and return the launcher's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")      # N GPUs of ONE node: RCCL's bootstrap over loopback
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver supports dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.write(2, f"bench.py: no launcher in the environment, starting {n} ranks: {' '.join(cmd[1:9])} bench.py ...\n".encode())
+    return subprocess.run(cmd, env=env).returncode
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner and gloo a connection note on fd 1 when a group comes up; the contract is ONE JSON
+    line on stdout, so fd 1 points at stderr while the group is brought up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,21 +232,48 @@ def main():
                          "every step goes through the gather")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--stage-timeout", type=float, default=120.0,
+                    help="seconds a start-up / collective stage may take before the rank exits with code 3 naming it "
+                         "(render stages get 10x this)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="bring the N ranks and their process group up, all-reduce the ranks, print one JSON line and stop "
+                         "(no GPU touched: the CPU rehearsal of the launch path)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import raytracingmin_amd as rtm
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # nothing below has run yet: no torch import, no GPU call in this process
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    from raytracingmin_amd.distributed import StageWatchdog
+    dog = StageWatchdog(limit_s=args.stage_timeout, rank=rank, quiet=(world == 1 and args.backend is None))
+    dog.enter("import torch")
+    import torch
+    import torch.distributed as dist
+    import raytracingmin_amd as rtm
+
+    args.gpus = world  # the launcher's world size is what runs
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        with stdout_to_stderr():
+            dog.enter(f"init_process_group({args.backend or 'gloo'}, world {world})")
+            dist.init_process_group(args.backend or "gloo", rank=rank, world_size=world)
+            dog.enter("all_reduce of the ranks")
+            t = torch.zeros(world, dtype=torch.int64)
+            t[rank] = rank + 1
+            dist.all_reduce(t)
+            dog.enter("destroy_process_group")
+            dist.destroy_process_group()
+        dog.done()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": [int(v) - 1 for v in t],
+                              "backend": args.backend or "gloo"}), flush=True)
+        return
     if args.same_device:
         local_rank = 0
+    dog.enter(f"torch.cuda.set_device({local_rank})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_group = world > 1 or args.backend is not None
@@ -219,24 +282,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # N GPUs of ONE node: RCCL's bootstrap over loopback
-        # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line
-        # there, so stdout points at stderr until the group has done its first collective
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():  # until the group has done its first collective
+            dog.enter(f"init_process_group({backend}, world {world}, NCCL_SOCKET_IFNAME={os.environ['NCCL_SOCKET_IFNAME']})")
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
+            dog.enter("first barrier (communicator bring-up)")
             dist.barrier()
             if backend == "nccl":
                 torch.cuda.synchronize(dev)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
     host_trig = not args.device_trig
+    dog.enter("scene load + renderer set-up")
 
     cfg = dict(HEADLINE, width=args.width, height=args.height, samples=args.samples,
                super_samples=args.super_samples, max_bounces=args.max_bounces)
@@ -288,6 +345,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    dog.enter(f"{args.warmup} warm-up step(s) + one instrumented step (render + gather)", 10 * args.stage_timeout)
     for _ in range(args.warmup):
         sr.step()
     # kernel time and counters of one instrumented launch (outside the timed region)
@@ -298,12 +356,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     barrier()
+    dog.enter(f"{args.steps} timed step(s) (render + gather)", 10 * args.stage_timeout)
     t0 = time.perf_counter()
     for k in range(args.steps):
         sr.step(events=ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
 
+    dog.enter("all_reduce(MAX) of the ranks' times")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if use_group:
@@ -313,6 +373,7 @@ def main():
 
     # SURVEY.md §8(d) wall time: kernel(s) + the final D2H of the frame (rank 0 holds it after the gather)
     with_d2h = None
+    dog.enter("extras: with_d2h steps, CPU baseline, other configs", 30 * args.stage_timeout)
     if not args.no_extras:
         host = torch.empty(sr.image.shape, dtype=sr.image.dtype, pin_memory=True) if rank == 0 and sr.image is not None else None
         barrier()
@@ -426,7 +487,9 @@ def main():
             line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig)
         print(json.dumps(line), flush=True)
     if use_group:
+        dog.enter("destroy_process_group")
         dist.destroy_process_group()
+    dog.done()
 
 
 if __name__ == "__main__":

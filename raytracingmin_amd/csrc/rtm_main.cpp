@@ -41,6 +41,11 @@ static void usage() {
 }
 
 int main(int argc, char* argv[]) {
+    // progress lines reach a pipe as they are printed (a caller that has to kill a stalled run still sees how far it got)
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);
+    // N GPUs of ONE node in ONE process: RCCL's bootstrap needs no more than the loopback interface, and a
+    // container's veth is not always connectable to itself.  Set before any thread exists; a user's value is kept.
+    (void)setenv("NCCL_SOCKET_IFNAME", "lo", 0);
     std::string json_file = "settingData.json", stem = "result";
     int width = 0, height = 0, samples = 0, super_samples = 0, spp = 0;
     int mode = RTM_MODE_REPAIRED, max_bounces = -1, device = 0, gpus = 1, virtual_strips = 0, host_trig = 1, force_rccl = 0;

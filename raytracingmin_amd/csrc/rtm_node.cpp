@@ -12,9 +12,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,6 +83,96 @@ struct Comms {
             if (v) (void)ncclCommDestroy(v);
     }
 };
+
+// Every step of the multi-GPU path announces itself on stderr (one write per line, never buffered), and a watchdog
+// thread ends the process — a fresh non-zero exit, code 3, naming the stage — when a stage does not finish within its
+// bound.  A run that stalls (a communicator that never comes up, a send/recv pair that never matches, a kernel that
+// never drains) therefore says WHERE it stalled instead of dying silently at its caller's limit.
+// Bounds: RTM_NODE_STAGE_TIMEOUT seconds for the set-up / RCCL / assembly stages (default 60), RTM_NODE_RENDER_TIMEOUT
+// for the render stage (default 0 = unbounded: a frame may legitimately take minutes); RTM_NODE_QUIET=1 drops the lines
+// (never the watchdog's).
+class Stages {
+  public:
+    Stages() {
+        stage_limit_ = env_seconds("RTM_NODE_STAGE_TIMEOUT", 60);
+        render_limit_ = env_seconds("RTM_NODE_RENDER_TIMEOUT", 0);
+        const char* q = std::getenv("RTM_NODE_QUIET");
+        quiet_ = q && q[0] == '1';
+        dog_ = std::thread([this] { watch(); });
+    }
+    ~Stages() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        dog_.join();
+    }
+    void enter(bool render_stage, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        std::vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            name_ = buf;
+            since_ = std::chrono::steady_clock::now();
+            limit_ = render_stage ? render_limit_ : stage_limit_;
+        }
+        say("stage: ", buf);
+        // test hook: RTM_NODE_DEBUG_STALL=<text> parks the calling thread in the first stage whose name contains
+        // <text>, which is how tests/test_cli_gpu.py shows that a stalled stage ends in exit code 3 with its name
+        const char* stall = std::getenv("RTM_NODE_DEBUG_STALL");
+        if (stall && *stall && std::strstr(buf, stall))
+            for (;;) ::pause();
+    }
+    void note(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        std::vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        say("", buf);
+    }
+
+  private:
+    static int env_seconds(const char* name, int dflt) {
+        const char* v = std::getenv(name);
+        return v && *v ? std::atoi(v) : dflt;
+    }
+    void say(const char* prefix, const char* text) const {
+        if (quiet_) return;
+        char line[320];
+        int n = std::snprintf(line, sizeof line - 1, "rtm_node: %s%s", prefix, text);
+        if (n > (int)sizeof line - 2) n = (int)sizeof line - 2;
+        line[n++] = '\n';
+        (void)!::write(2, line, (size_t)n);  // one write(2) per line: nothing to flush, nothing to interleave
+    }
+    void watch() {
+        std::unique_lock<std::mutex> g(m_);
+        while (!stop_) {
+            cv_.wait_for(g, std::chrono::milliseconds(500));
+            if (stop_ || limit_ <= 0 || name_.empty()) continue;
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - since_).count();
+            if (waited > limit_) {
+                char line[400];
+                const int n = std::snprintf(line, sizeof line,
+                                            "rtm_node: WATCHDOG: stage '%s' has not finished after %d s; exiting with code 3\n",
+                                            name_.c_str(), limit_);
+                (void)!::write(2, line, (size_t)n);
+                ::_exit(3);
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::string name_;
+    std::chrono::steady_clock::time_point since_{};
+    int limit_ = 0, stage_limit_ = 60, render_limit_ = 0;
+    bool stop_ = false, quiet_ = false;
+    std::thread dog_;
+};
 }  // namespace
 
 int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n, const rtm_options* base,
@@ -87,6 +183,7 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
     const size_t px_bytes = 3 * sizeof(float) + 3;  // float3 + rgb8 per pixel
     // virtual_strips > 0: that many parts, all on base->device (exercises the tiling on one GPU)
     const int parts = virtual_strips > 0 ? virtual_strips : n_devices;
+    Stages stages;  // first, so that it outlives (and watches) the release of everything below
     std::vector<Part> part(parts);
     std::vector<size_t> stage_off(parts + 1, 0);
     for (int r = 0; r < parts; ++r) {
@@ -104,6 +201,7 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
     const int root = part[0].dev;
     for (int r = 0; r < parts; ++r) {
         Part& p = part[r];
+        stages.enter(false, "set-up of part %d of %d on device %d (stream, band stack, scene upload)", r, parts, p.dev);
         NODE_HIP(hipSetDevice(p.dev));
         NODE_HIP(hipStreamCreate(&p.stream));
         if (p.rows) NODE_HIP(hipMalloc((void**)&p.strip, p.rows * W * px_bytes));
@@ -120,7 +218,9 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
         uint8_t* u8 = p.strip ? p.strip + p.rows * W * 3 * sizeof(float) : nullptr;
         p.rc = rtm_render_scene(st, p.scene, &p.opt, nullptr, f32, u8, p.stream, &p.stats);
         if (p.rc != RTM_OK) p.detail = rtm_last_error_detail();
+        stages.note("part %d rendered on device %d: rc %d, %.3f ms of kernels", r, p.dev, p.rc, p.stats.kernel_ms);
     };
+    stages.enter(true, "render of %d part(s): %dx%d, %zu row(s) in the largest", parts, W, H, part[0].rows);
     if (virtual_strips > 0) {
         for (int r = 0; r < parts; ++r) work(r);
     } else {
@@ -137,6 +237,7 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
     // gather on the root device: the band stacks land side by side in a staging buffer ...
     RootBuffers rb;
     rb.dev = root;
+    stages.enter(false, "frame buffers on the root device %d", root);
     NODE_HIP(hipSetDevice(root));
     NODE_HIP(hipMalloc((void**)&rb.full32, (size_t)W * H * 3 * sizeof(float)));
     NODE_HIP(hipMalloc((void**)&rb.full8, (size_t)W * H * 3));
@@ -147,13 +248,16 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
     } else {
         NODE_HIP(hipMalloc((void**)&rb.stage, stage_off[parts] ? stage_off[parts] : 1));
         // one process, one node: RCCL's bootstrap needs no more than the loopback interface (a container's veth is
-        // not always usable for it); an NCCL_SOCKET_IFNAME the user has set is respected
-        (void)setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+        // not always usable for it); rtm_cli's main() sets NCCL_SOCKET_IFNAME=lo before anything else runs unless the
+        // user has set one — here, with HIP threads alive, the environment is only read
+        const char* ifname = std::getenv("NCCL_SOCKET_IFNAME");
         Comms comms;
         comms.c.assign(parts, nullptr);
         std::vector<int> devs(parts);
         for (int r = 0; r < parts; ++r) devs[r] = part[r].dev;
+        stages.enter(false, "ncclCommInitAll over %d device(s), bootstrap interface %s", parts, ifname ? ifname : "(RCCL's choice)");
         NODE_NCCL(ncclCommInitAll(comms.c.data(), parts, devs.data()));
+        stages.enter(false, "grouped ncclSend/ncclRecv of %zu bytes into device %d", stage_off[parts], root);
         NODE_NCCL(ncclGroupStart());
         for (int r = 0; r < parts; ++r) {
             src[r] = rb.stage + stage_off[r];
@@ -164,13 +268,16 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
         }
         NODE_NCCL(ncclGroupEnd());
         for (int r = 0; r < parts; ++r) {
+            stages.enter(false, "stream synchronise after the exchange, part %d on device %d", r, part[r].dev);
             NODE_HIP(hipSetDevice(part[r].dev));
             NODE_HIP(hipStreamSynchronize(part[r].stream));
         }
         NODE_HIP(hipSetDevice(root));
+        stages.enter(false, "ncclCommDestroy of %d communicator(s)", parts);
     }
     // ... and band b of the image is band b / parts of part b % parts
     const int bands = (H + 7) / 8;
+    stages.enter(false, "de-interleave of %d band(s) on the root device + copy to the host", bands);
     for (int b = 0; b < bands; ++b) {
         const int rows = (H - b * 8 < 8) ? H - b * 8 : 8;
         const Part& p = part[b % parts];
@@ -200,5 +307,6 @@ int rtm_node_render(const rtm_settings* st, const rtm_object* objects, size_t n,
             total->split = s.split;
         }
     }
+    stages.enter(false, "release of the parts' scenes, buffers and streams");
     return RTM_OK;
 }

@@ -101,6 +101,58 @@ def gather_strips(local, strips, rank, world, dst=0, group=None):
     return torch.cat([bufs[r][: strips[r][1] - strips[r][0]] for r in range(world)], dim=0)
 
 
+class StageWatchdog:
+    """Names and bounds the stages of a rank's start-up and collectives (the Python mirror of csrc/rtm_node.cpp's
+    watchdog).  enter(name) prints `[rank r] stage: name` on stderr (and to `stage_file`, if given) and re-arms the
+    limit; a stage that is still running after `limit_s` seconds ends the PROCESS with exit code 3 and a line naming
+    it — a fresh non-zero exit (os._exit), never a re-exec — so a launcher sees a failed rank with a located cause
+    instead of a job that dies silently at its caller's limit.  done() disarms it."""
+
+    def __init__(self, limit_s=120.0, rank=0, stage_file=None, quiet=False):
+        import threading
+        self.limit_s, self.rank, self.stage_file, self.quiet = float(limit_s), rank, stage_file, quiet
+        self._name, self._since, self._stop = None, 0.0, False
+        self._lock = threading.Lock()
+        self._thread = threading.Thread(target=self._watch, name="rtm-stage-watchdog", daemon=True)
+        self._thread.start()
+
+    def _say(self, text):
+        import os
+        os.write(2, (f"[rank {self.rank}] {text}\n").encode())
+
+    def enter(self, name, limit_s=None):
+        import time
+        with self._lock:
+            self._name, self._since = name, time.monotonic()
+            self._limit = self.limit_s if limit_s is None else float(limit_s)
+        if not self.quiet:
+            self._say(f"stage: {name}")
+        if self.stage_file:
+            with open(self.stage_file, "w") as f:
+                f.write(name)
+
+    def done(self):
+        with self._lock:
+            self._name = None
+
+    def _watch(self):
+        import os
+        import time
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                name, since, limit = self._name, self._since, getattr(self, "_limit", self.limit_s)
+            if name is not None and limit > 0 and time.monotonic() - since > limit:
+                self._say(f"WATCHDOG: stage '{name}' has not finished after {limit:.0f} s; exiting with code 3")
+                if self.stage_file:
+                    try:
+                        with open(self.stage_file, "w") as f:
+                            f.write(f"WATCHDOG: {name}")
+                    except OSError:
+                        pass
+                os._exit(3)
+
+
 class StripRenderer:
     """Rank-local renderer of this rank's share of the rows plus the end-of-step gather (bench.py's
     step).  layout "bands": interleaved 8-row bands (default); "strips": contiguous strips."""

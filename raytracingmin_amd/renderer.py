@@ -37,9 +37,14 @@ class Renderer:
 
     # ---- the scene on the device: flattened and uploaded once per renderer -------------------
     def _scene_handle(self):
-        """rtm_scene_create once; made again only when the object list was replaced or resized
-        (call invalidate() after editing spheres in place)."""
-        key = (id(self.data.object), len(self.data.object))
+        """rtm_scene_create once; made again whenever the scene may have changed since — the reference reads the live
+        SettingData at render time (src/Renderer.h:16), and so must this: the key holds the identities of the list's
+        objects in order (replaced, reordered, added, removed entries) and the edit epoch of settings.py (any field of
+        any scene object written in place).  A needless re-flatten after unrelated edits costs a re-upload that the
+        library's content-addressed scene cache makes cheap; a stale scene is never rendered."""
+        from .settings import edit_epoch
+        objs = self.data.object
+        key = (edit_epoch(), len(objs), hash(tuple(map(id, objs))))
         if self._scene is None or key != self._scene_key:
             self.invalidate()
             h = C.c_void_p()

@@ -13,8 +13,26 @@ from . import _lib
 from ._lib import rtm_object, rtm_settings, rtm_sphere
 
 
+_EDITS = [0]  # bumped by every attribute write on a scene object (construction included)
+
+
+def edit_epoch():
+    """Changes whenever any vec3 / Material / SphereObject / PlaneObject was written to or constructed: with the
+    identities of a scene's objects it tells a Renderer that its uploaded copy may be stale (renderer.py).  The
+    reference reads the live SettingData at render time (src/Renderer.h:16); so does this mirror."""
+    return _EDITS[0]
+
+
+class _Tracked:
+    __slots__ = ()
+
+    def __setattr__(self, name, value):
+        _EDITS[0] += 1
+        object.__setattr__(self, name, value)
+
+
 @dataclass
-class vec3:  # src/Ray.h:7-12
+class vec3(_Tracked):  # src/Ray.h:7-12
     x: float = 0.0
     y: float = 0.0
     z: float = 0.0
@@ -24,20 +42,20 @@ class vec3:  # src/Ray.h:7-12
 
 
 @dataclass
-class Material:  # src/SettingData.h:8-17
+class Material(_Tracked):  # src/SettingData.h:8-17
     color: vec3 = field(default_factory=vec3)
     emission: vec3 = field(default_factory=vec3)
 
 
 @dataclass
-class SphereObject:  # src/SettingData.h:25-32; m_size is a float in the reference
+class SphereObject(_Tracked):  # src/SettingData.h:25-32; m_size is a float in the reference
     m_position: vec3 = field(default_factory=vec3)
     m_size: float = 1.0
     m_material: Material = field(default_factory=Material)
 
 
 @dataclass
-class PlaneObject:
+class PlaneObject(_Tracked):
     """png::PlaneObject(position, up, target, width, mat) — src/SettingData.h:33-42, src/SettingData.cpp:235-242.
     The reference leaves its Intersect unfinished; this build completes it as the finite square the constructor
     describes (include/rtm.h: rtm_object) — a build-defined semantics."""

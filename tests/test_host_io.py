@@ -200,3 +200,24 @@ def test_plane_objects_in_the_oracle(oracle):
     for k, v in enumerate((0.0, 0.0, 6.0)):
         sp.center[k] = v
     assert oracle.intersect_object(s, (0.1, 0.2, 0), (0, 0, 1), 1) == oracle.intersect(sp, (0.1, 0.2, 0), (0, 0, 1), 1)
+
+
+def test_edit_epoch_sees_every_write_on_a_scene_object():
+    """settings.edit_epoch(): what lets a Renderer notice in-place edits of the caller's SettingData (the reference
+    reads the live scene at render time); identities of the list's entries cover replacement and reordering."""
+    import _oracle
+    from raytracingmin_amd.settings import edit_epoch
+    data = rtm.LoadData(_oracle.scene_path("cornellBoxSetting.json")).data
+    e0 = edit_epoch()
+    data.object[0].m_position.x = 1.5
+    e1 = edit_epoch()
+    data.object[0].m_material.emission.z = 2.0
+    e2 = edit_epoch()
+    data.object[0].m_size = 4.0
+    e3 = edit_epoch()
+    assert e0 < e1 < e2 < e3
+    ids = tuple(map(id, data.object))
+    data.object[1], data.object[2] = data.object[2], data.object[1]
+    assert tuple(map(id, data.object)) != ids and edit_epoch() == e3  # reordering writes nothing: the ids catch it
+    rtm.PlaneObject()
+    assert edit_epoch() > e3                                           # construction counts (conservative)

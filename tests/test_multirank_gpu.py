@@ -94,16 +94,23 @@ def test_strips_from_n_ranks_equal_single_rank_frame(world, dims):
     assert np.array_equal(img_bands.view(np.uint64), full["f64"].view(np.uint64))
 
 
-def _rccl_worker(port, scene, dims, q):
+def _rccl_worker(port, scene, dims, q, stage_path):
     """ONE rank, backend nccl (= RCCL): the N-rank step with the collective forced — communicator init,
-    dist.gather on device tensors, the de-interleave on the root."""
-    import torch
-    import torch.distributed as dist
+    dist.gather on device tensors, the de-interleave on the root.  Every stage is written to `stage_path` before it
+    starts and bounded by raytracingmin_amd.distributed.StageWatchdog (exit code 3 with the stage's name)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    from raytracingmin_amd.distributed import StageWatchdog
+    dog = StageWatchdog(limit_s=60, stage_file=stage_path)
+    dog.enter("import torch")
+    import torch
+    import torch.distributed as dist
+    dog.enter("torch.cuda.set_device(0)")
     torch.cuda.set_device(0)
+    dog.enter("init_process_group(nccl, world 1, lo)")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dog.enter("renders + dist.gather over RCCL")
     try:
         import raytracingmin_amd as rtm
         from raytracingmin_amd.distributed import StripRenderer, gather_bands, gather_strips
@@ -123,12 +130,15 @@ def _rccl_worker(port, scene, dims, q):
         g2 = gather_strips(t, [(0, 45)], 0, 1)
         torch.cuda.synchronize()
         q.put((out["bands"], out["strips"], bool(torch.equal(g, t)) and bool(torch.equal(g2, t))))
+        dog.enter("final barrier")
         dist.barrier()
     finally:
+        dog.enter("destroy_process_group")
         dist.destroy_process_group()
+        dog.done()
 
 
-def test_one_rank_rccl_process_group_runs_the_gather():
+def test_one_rank_rccl_process_group_runs_the_gather(tmp_path):
     """torch.distributed over RCCL has run on this box: world size 1, the step's gather forced."""
     import torch.multiprocessing as mp
     import _oracle
@@ -137,14 +147,14 @@ def test_one_rank_rccl_process_group_runs_the_gather():
     dims = (88, 45, 2, 2)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rccl_worker, args=(_free_port(), scene, dims, q))]
+    stage_file = tmp_path / "stage.txt"
+    procs = [ctx.Process(target=_rccl_worker, args=(_free_port(), scene, dims, q, str(stage_file)))]
     procs[0].start()
     try:
         (bands, strips, ok), = _collect(procs, q, 1, timeout=150)
     except WorkersTimedOut:
-        # RCCL's communicator initialisation is the one step here that has been seen not to return on a box (see
-        # tests/test_cli_gpu.py): an environment matter, not failed on
-        pytest.xfail("the one-rank RCCL process group did not come up within 150 s on this box")
+        stage = stage_file.read_text() if stage_file.exists() else "(worker never started)"
+        pytest.fail(f"the one-rank RCCL worker did not deliver within 150 s; its last stage: {stage!r}")
     assert ok
     data = rtm.LoadData(scene).data
     data.width, data.height, data.samples, data.superSamples = dims

@@ -1340,3 +1340,42 @@ def test_renders_on_two_streams_from_two_threads(rtm, oracle):
         assert len(got[j]) == 5
         for f in got[j]:
             assert _bits_equal(f.cpu().numpy(), want[j]), j
+
+
+def test_renderer_reads_the_live_scene(rtm, oracle):
+    """png::Renderer holds a reference to the caller's SettingData and reads it at render time (src/Renderer.h:16).
+    The mirror keeps an uploaded copy, so it must notice every way the scene can change between two calls: a field
+    written in place, an entry replaced by one of another type at the same index, entries reordered — on the
+    device-resident entry point and on the host one alike."""
+    data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    data.width, data.height, data.samples, data.superSamples = 64, 40, 2, 2
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=11)
+
+    def both():
+        dev, _ = r.render_rows_device(want=("f64",))
+        host, _ = r.render_rows(want=("f64",))
+        fresh, _ = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=11).render_rows_device(want=("f64",))
+        dev, fresh = dev["f64"].cpu().numpy(), fresh["f64"].cpu().numpy()
+        assert _bits_equal(dev, host["f64"]) and _bits_equal(dev, fresh)
+        oobj, n = _oracle_objects(oracle, data)
+        ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
+        ref, _ = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=1, max_bounces=8, seed=11, height=40))
+        assert _bits_equal(dev, ref)
+        return dev
+
+    a = both()
+    handle = r._scene.value
+    assert _bits_equal(both(), a) and r._scene.value == handle       # nothing changed: the uploaded scene is reused
+    data.object[0].m_position.y = 8.5                                 # in place, two levels down
+    data.object[1].m_material.color.x = 0.3
+    b = both()
+    assert not _bits_equal(a, b)
+    data.object[0].m_size = 3.0                                       # in place, a scalar field
+    c = both()
+    assert not _bits_equal(b, c)
+    data.object[0] = rtm.PlaneObject(rtm.vec3(0, 7, 0), rtm.vec3(0, 0, 1), rtm.vec3(0, 0, 0), 6.0,
+                                     rtm.Material(rtm.vec3(0, 0, 0), rtm.vec3(5, 5, 5)))  # another type, same index
+    d = both()
+    assert not _bits_equal(c, d)
+    data.object[1], data.object[2] = data.object[2], data.object[1]  # reorder: same objects, nothing written
+    both()
