@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTM_ABI_VERSION 3
+#define RTM_ABI_VERSION 4
 
 typedef enum rtm_status {
     RTM_OK = 0,
@@ -137,8 +137,10 @@ typedef struct rtm_stats {
 
 /* A scene flattened to the kernels' layout and resident on one device (opaque).  Created once,
  * used by any number of renders on any stream of that device, destroyed by the caller after the
- * last render that uses it has been enqueued (the library defers the release of the device
- * memory until that work has finished). */
+ * last render that uses it has been ENQUEUED: rtm_scene_destroy does not wait for that work.  When the
+ * renders that named the scene have all finished, its device memory is freed in the call; otherwise the
+ * scene is parked and freed by a later library call (any render, create or destroy) that finds them
+ * finished, or by rtm_release_scratch, which waits.  Other streams of the device are never waited for. */
 typedef struct rtm_scene rtm_scene;
 
 /* ---- library ---- */
@@ -154,8 +156,17 @@ int rtm_output_rows(const rtm_options* options);
 /* The library keeps its large work buffers (per device and stream, grown on demand), the scene cache
  * of rtm_render_device and the RTM_MODE_HOST_TRIG tables between calls; this frees them for one
  * device, or for all with device < 0.  Waits for the device to go idle.  Scenes made by
- * rtm_scene_create are the caller's and stay. */
+ * rtm_scene_create are the caller's and stay.
+ * What "large" means: the sample split of a launch's last tiles keeps 2 KiB per (split tile, deferred sample) —
+ * 1.6 GB for the headline frame, capped at 24 GiB per stream (a launch whose terms would not fit splits fewer
+ * tiles, or none); unlimited-depth renders keep two pooled record stacks per lane (5.5 GB for a 1080p frame);
+ * the large-scene pipeline ~300 B per pixel plus 4 B per pixel and record level. */
 int rtm_release_scratch(int device);
+/* The same for ONE stream: waits for that stream's queued work, frees the buffers and the sticky status word the
+ * library keeps for (device, stream) and forgets the pair.  Call it before destroying a stream that has rendered
+ * (a later stream may be given the same handle and would inherit the context otherwise).  An overflow that was
+ * never reported is returned here (RTM_ERR_UNSUPPORTED), like rtm_stream_status would. */
+int rtm_stream_release(int device, void* stream);
 
 /* ---- scene lifetime: png::SettingData::object (src/SettingData.h:47-51) on the device ----
  * rtm_scene_create flattens `spheres` (HOST pointer, or a DEVICE pointer on `device` when
@@ -177,8 +188,10 @@ size_t rtm_scene_size(const rtm_scene* scene);
  * out_f32 is the same value rounded to float (the float3 accumulation buffer); out_u8 is the
  * reference's 8-bit quantisation (src/Renderer.cpp:251-254).
  *
- * rtm_render_scene with stats == NULL only ENQUEUES work on `stream` and returns: no allocation that
- * synchronises, no copy from pageable memory, no wait (scenes of 512 spheres or more: the
+ * rtm_render_scene with stats == NULL only ENQUEUES work on `stream` and returns: no copy from pageable
+ * memory and no wait — except that the FIRST call on a (device, stream) pair sets up its context, and a call
+ * that needs a larger work buffer than the pair has (see rtm_release_scratch) grows it, which allocates and
+ * waits for that stream's queued work once; steady-state calls do neither (scenes of 512 spheres or more: the
  * large-scene pipeline is a host loop of launches that follows the device-resident active-pixel
  * count one batch of trips behind; the call returns when the last batch has been enqueued and the
  * count has been seen at zero, i.e. it blocks for about the duration of the render).

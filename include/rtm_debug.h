@@ -20,9 +20,9 @@ extern "C" {
 int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, double* out);
 /* exhaustive device self-checks; *mismatches = number of failing inputs (kind 0: fast sqrtf) */
 int rtm_debug_selfcheck(int kind, unsigned long long* mismatches);
-/* the large-scene nearest-hit kernels on caller-given rays: kind 0 LDS tiles, 1 scalar stream,
- * 2 + fp64 rejection test, 3 + packed-fp32 rejection test (two spheres per instruction: the default),
- * 4 the same with two rays per instruction (A/B twin) */
+/* nearest hit for caller-given rays: kind 1 the reference's loop as written (src/Renderer.cpp:58-73, the compiler's
+ * math, nothing in front of it), kind 3 the large-scene kernel (packed-fp32 rejection test + per-lane candidate lists
+ * in front of the same arithmetic); any other kind is RTM_ERR_INVALID_ARGUMENT */
 int rtm_debug_wf_nearest(int kind, const rtm_sphere* spheres, size_t n, const double* org, const double* dir,
                          size_t n_rays, int32_t* out_id, double* out_t);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */

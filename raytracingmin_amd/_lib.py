@@ -72,6 +72,7 @@ SIGNATURES = {
     "rtm_device_count": (C.c_int, [_P(C.c_int)]),
     "rtm_output_rows": (C.c_int, [_P(rtm_options)]),
     "rtm_release_scratch": (C.c_int, [C.c_int]),
+    "rtm_stream_release": (C.c_int, [C.c_int, C.c_void_p]),
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
     "rtm_scene_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -120,7 +121,7 @@ DEBUG_SIGNATURES = {
     "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_double)]),
 }
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

@@ -17,6 +17,7 @@ int device_count(int* count);
 int num_variants();
 int output_rows(const rtm_options* opt);
 int release_scratch(int device);
+int stream_release(int device, void* stream);
 int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                      int32_t* out_id, double* out_t);
 const char* variant_name(int v);

@@ -741,133 +741,6 @@ __global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P
     store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Large scenes (BASELINE configs[4]: 100 k spheres): the sphere list is streamed HBM/L2 -> LDS in
-// tiles of TILE spheres by the whole 256-thread workgroup with coalesced 16-byte loads (double
-// buffered: the next tile is fetched into registers while the current one is tested), and every lane
-// of the four waves reads the same LDS address per sphere (broadcast, conflict-free).  One
-// workgroup = four 8x8 pixel tiles side by side; all lanes of the block run the nearest-hit loop in
-// lock-step (it contains the barriers), shading and path bookkeeping are per lane as in
-// render_tiles_kernel.  Index order and strict < are preserved across tiles, so the lowest index
-// still wins exact ties.
-template <class M, typename RecT, int LDS_D, int TILE>
-__global__ __launch_bounds__(256) void render_scene_tiled_kernel(const RenderParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double2* tile_buf = reinterpret_cast<double2*>(lds_raw);            // 2 x TILE x 2 double2
-    RecT* rec_all = reinterpret_cast<RecT*>(tile_buf + 2 * TILE * 2);  // 4 waves x LDS_D x 64
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    RecT* rec = rec_all + wave * LDS_D * 64;
-    constexpr int CHUNKS = TILE * 2 / 256;  // 16-byte chunks per thread per tile
-
-    SceneGlobal sc;
-    sc.v = P.scene;
-    const int n = P.scene.n;
-    const int n_tiles = (n + TILE - 1) / TILE;
-    const double2* gsrc = reinterpret_cast<const double2*>(P.scene.geom);
-    const int n_chunks = n * 2;
-
-    const int tiles_x4 = (P.tiles_x + 3) / 4;
-    const int tx = (blockIdx.x % tiles_x4) * 4 + wave, ty = blockIdx.x / tiles_x4;
-    const int x = tx * 8 + (lane & 7);
-    const int y = band_row(P, ty, lane >> 3);
-    const bool valid = (x < P.W) && (y < P.row_end);
-    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-
-    PathCounters pc = {0, 0, 0};
-    RecordStack<RecT, LDS_D> stack{rec, lane, &P};
-    D3 acc = d3(0, 0, 0);
-    unsigned ns = valid ? 0u : P.total_samples;
-    int s_in_sub = 0, sub = 0;
-    D3 pdir = primary_dir(P, x, y, 1, 1);
-    D3 org = P.cam_org, dir = pdir;
-    int depth = 0;
-    const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
-    RngStream rng = rng_open(pkey, 0u);
-    auto push = [&](int d, int id) { stack.push(d, id); };
-    auto pop = [&](int d) -> int { return stack.pop(d); };
-    const bool pow2 = P.inv_s != 0.0;
-
-    while (__syncthreads_or(ns < P.total_samples)) {
-        // ---- nearest hit over the whole scene, tile by tile (src/Renderer.cpp:62-72) ----
-        double dis = DBL_MAX;
-        int id = -1;
-        if (n_tiles > 0) {
-#pragma unroll
-            for (int k = 0; k < CHUNKS; ++k) {
-                const int c = k * 256 + tid;
-                tile_buf[c] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
-            }
-        }
-        __syncthreads();
-        for (int t = 0; t < n_tiles; ++t) {
-            double2 pre[CHUNKS];
-            const bool more = (t + 1 < n_tiles);
-            if (more) {
-#pragma unroll
-                for (int k = 0; k < CHUNKS; ++k) {
-                    const int c = (t + 1) * TILE * 2 + k * 256 + tid;
-                    pre[k] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
-                }
-            }
-            const int base = t * TILE;
-            const int cnt = (n - base < TILE) ? (n - base) : TILE;
-            // the tile as a "scene": every lane reads the same LDS address per sphere (broadcast)
-            struct TileGeom {
-                const double2* cur;
-                int base;
-                __device__ __forceinline__ double4 geom_uniform(int i) const {
-                    const double2 a = cur[2 * (i - base)], b = cur[2 * (i - base) + 1];
-                    return double4{a.x, a.y, b.x, b.y};
-                }
-            } tile{tile_buf + (t & 1) * TILE * 2, base};
-            int j = 0;
-            for (; j + 8 <= cnt; j += 8) sphere_chunk<M, 8, TileGeom, true>(tile, base + j, org, dir, dis, id);
-            for (; j < cnt; ++j) sphere_chunk<M, 1, TileGeom, true>(tile, base + j, org, dir, dis, id);
-            if (more) {
-                double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
-#pragma unroll
-                for (int k = 0; k < CHUNKS; ++k) nxt[k * 256 + tid] = pre[k];
-            }
-            __syncthreads();
-        }
-        // ---- shade / bookkeeping, per lane ----
-        if (ns < P.total_samples) {
-            D3 term;
-            bool cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push);
-            if (cont && stack.overflow) {
-                cont = false;
-                term = d3(0, 0, 0);
-                depth = 0;
-            }
-            if (!cont) {
-                const bool deep = depth > LDS_D;
-                const D3 L = (__builtin_amdgcn_ballot_w64(deep) == 0)
-                                 ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
-                                 : path_fold(sc, term, depth, pop);
-                const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
-                acc = acc + clamp01_d3(cal);
-                ++ns;
-                if (++s_in_sub == P.S) {
-                    s_in_sub = 0;
-                    ++sub;
-                    if (ns < P.total_samples) pdir = primary_dir(P, x, y, sub / P.SS + 1, sub % P.SS + 1);
-                }
-                org = P.cam_org;
-                dir = pdir;
-                depth = 0;
-                rng = rng_open(pkey, ns);
-            }
-        }
-    }
-    store_pixel(P, valid, x, y, acc);
-    if (P.counters) {
-        wave_add_counter(P.counters + 0, pc.casts);
-        wave_add_counter(P.counters + 1, pc.bounces);
-        wave_add_counter(P.counters + 2, pc.draws);
-        if (stack.overflow) atomicOr(P.counters + 3, 1ull);
-    }
-}
-
 }  // namespace rtm
 #include "rtm_wavefront.h"
 #include "rtm_fp32.h"
@@ -981,6 +854,23 @@ __global__ void rng_batch_kernel(uint64_t seed_mult, uint32_t pixel0, uint32_t n
 // ------------------------------------------------------------------------------------------------
 // Component micro-benchmarks (profiles/component_bench.py): the nearest-hit loop and the shading
 // block in isolation, timed with s_memtime, same policies as the render kernel.
+// src/Renderer.cpp:58-73 as written, one lane per ray (SoA rays): the yardstick of rtm_debug_wf_nearest
+__global__ __launch_bounds__(256) void nearest_probe_kernel(SceneView scene, const double* __restrict__ org,
+                                                            const double* __restrict__ dir, unsigned n_rays,
+                                                            int* __restrict__ out_id, double* __restrict__ out_t) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned r = i < n_rays ? i : n_rays - 1u;
+    SceneGlobal sc;
+    sc.v = scene;
+    double dis;
+    const int id = nearest_hit<MathRef, 1>(sc, d3(org[r], org[n_rays + r], org[2 * (size_t)n_rays + r]),
+                                           d3(dir[r], dir[n_rays + r], dir[2 * (size_t)n_rays + r]), dis);
+    if (i < n_rays) {
+        out_id[i] = id;
+        out_t[i] = dis;
+    }
+}
+
 template <class M, int UNROLL>
 __global__ __launch_bounds__(64) void nearest_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
                                                            unsigned long long* cycles) {
@@ -1261,7 +1151,16 @@ struct rtm_scene {
     size_t n = 0;
     rtm::DevMem geom, mat, aux, plane;  // plane: 16 doubles per object, only for scenes that hold planes
     bool has_planes = false;
-    uint64_t content_hash = 0;  // cache entries only
+    uint64_t content_hash = 0;            // cache entries only ...
+    std::vector<unsigned char> content;   // ... and the bytes the hash was taken of (compared on a hash hit)
+    // Streams that have rendered from this scene, one event each, re-recorded behind every render that names the scene:
+    // rtm_scene_destroy looks at them instead of waiting for the device (scene_destroy below).
+    mutable std::mutex use_mu;
+    mutable std::vector<std::pair<hipStream_t, hipEvent_t>> uses;
+    ~rtm_scene() {
+        for (auto& u : uses)
+            if (u.second) (void)hipEventDestroy(u.second);
+    }
 };
 
 namespace rtm {
@@ -1437,12 +1336,96 @@ int intersect_objects_batch(const rtm_object* objs, const double* org, const dou
     return RTM_OK;
 }
 
+// ---- scene release ------------------------------------------------------------------------------------------------
+// include/rtm.h: a scene may be destroyed as soon as the last render that uses it has been ENQUEUED, and the call
+// does not wait for that work.  Every render records an event behind its launches on its stream (note_scene_use);
+// destroy frees the tables at once when all of them have completed, and otherwise parks the scene in a process-wide
+// list that later library calls (and rtm_release_scratch, which does wait) reap with hipEventQuery.  The list is a
+// heap object that is never destroyed: nothing here calls HIP from a static destructor at process exit.
+namespace {
+struct Graveyard {
+    std::mutex mu;
+    std::vector<rtm_scene*> parked;
+};
+Graveyard& graveyard() {
+    static Graveyard* g = new Graveyard;
+    return *g;
+}
+struct DeviceGuard {  // the caller's current device is restored on every path
+    int prev = -1;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        (void)hipGetLastError();
+    }
+};
+bool scene_idle(const rtm_scene* sc, bool wait) {
+    std::lock_guard<std::mutex> lock(sc->use_mu);
+    for (auto& u : sc->uses) {
+        if (!u.second) continue;
+        if (wait) {
+            (void)hipEventSynchronize(u.second);
+        } else if (hipEventQuery(u.second) == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+static void note_scene_use(const rtm_scene* sc, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(sc->use_mu);
+    for (auto& u : sc->uses)
+        if (u.first == stream) {
+            (void)hipEventRecord(u.second, stream);
+            return;
+        }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    (void)hipEventRecord(e, stream);
+    sc->uses.emplace_back(stream, e);
+}
+
+// Free every parked scene whose renders have finished (wait: all of them, after waiting).  Never blocks otherwise.
+static void reap_scenes(bool wait, int device = -1) {
+    std::vector<rtm_scene*> done;
+    {
+        Graveyard& g = graveyard();
+        std::lock_guard<std::mutex> lock(g.mu);
+        if (g.parked.empty()) return;
+        for (auto it = g.parked.begin(); it != g.parked.end();) {
+            if ((device < 0 || (*it)->device == device) && scene_idle(*it, wait)) {
+                done.push_back(*it);
+                it = g.parked.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    if (done.empty()) return;
+    DeviceGuard guard;
+    for (rtm_scene* sc : done) {
+        (void)hipSetDevice(sc->device);
+        delete sc;
+    }
+}
+
 int scene_destroy(rtm_scene* sc) {
     if (!sc) return RTM_OK;
-    // renders that use the scene may still be queued: wait for the device before its memory goes
-    if (hipSetDevice(sc->device) == hipSuccess) (void)hipDeviceSynchronize();
-    (void)hipGetLastError();
-    delete sc;
+    reap_scenes(false);
+    if (scene_idle(sc, false)) {
+        DeviceGuard guard;
+        (void)hipSetDevice(sc->device);
+        delete sc;
+    } else {  // renders from it are still queued or running: its memory goes when they have finished
+        Graveyard& g = graveyard();
+        std::lock_guard<std::mutex> lock(g.mu);
+        g.parked.push_back(sc);
+    }
     return RTM_OK;
 }
 size_t scene_size(const rtm_scene* sc) { return sc ? sc->n : 0; }
@@ -1583,23 +1566,30 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
 }
 
 // variant 0 = auto (the fastest parity-validated kernel for the scene size)
+// Retired numbers keep their place (profiles of rounds 1-2 refer to them) and are refused with RTM_ERR_UNSUPPORTED; the
+// kernels behind them live in profiles/r3/retired_variants.patch, with the A/B results that retired them.
+#define RTM_RETIRED(what) "retired: " what " (profiles/r3/retired_variants.patch)"
 static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-math-lds-tables-chunk8-park-pack8",
-                                      "fast-math-global-scene-chunk8", "fast-math-lds-scene-tiles",
-                                      "fast-math-lds-tables-chunk8-nopark-pack8", "fast-math-lds-tables-chunk8-park-ldsrecords",
+                                      "fast-math-global-scene-chunk8", RTM_RETIRED("monolithic LDS scene tiles"),
+                                      RTM_RETIRED("variant 2 without the LDS-resident accumulator"),
+                                      RTM_RETIRED("variant 2 with LDS record stacks"),
                                       "diagnostic-stamped (segment cycle shares, not for timing)",
-                                      "wavefront-lds-scene-tiles",
+                                      RTM_RETIRED("wavefront pipeline, LDS scene tiles"),
                                       "fast-math-lds-tables-chunk8-park-pack8-sample-split",
-                                      "wavefront-scalar-scene", "wavefront-scalar-scene-reject",
+                                      RTM_RETIRED("wavefront pipeline, scalar scene stream without a rejection test"),
+                                      RTM_RETIRED("wavefront pipeline, fp64 rejection test"),
                                       "wavefront-scalar-scene-reject-f32",
-                                      "fast-math-lds-tables-chunk8-park-pack8-immediate-fold",
+                                      RTM_RETIRED("variant 2 with the immediate fold"),
                                       "fast-math-global-scene-chunk8-park-pack8",
                                       ("LABELLED-primary-hit-reuse (one nearest-hit search per sub-pixel for its S primary rays; "
                                        "not the reference's work per sample)"),
                                       ("LABELLED-fp32-fast (single precision, hardware sqrt/rsq/sin/cos, fused multiply-adds, "
                                        "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)")};
-constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3,
-              kVariantSceneTiled = 4, kVariantWavefront = 8, kVariantSplit = 9, kVariantWavefrontScalar = 10, kVariantWavefrontReject = 11, kVariantWavefrontRejectF32 = 12, kVariantImmediateFold = 13, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15, kVariantFp32 = 16;
-constexpr int kSceneTile = 512;  // spheres per LDS tile (2 x 16 KiB double buffer)
+#undef RTM_RETIRED
+constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3, kVariantStamped = 7,
+              kVariantSplit = 9, kVariantWavefrontRejectF32 = 12, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15,
+              kVariantFp32 = 16;
+static bool variant_retired(int v) { return v == 4 || v == 5 || v == 6 || v == 8 || v == 10 || v == 11 || v == 13; }
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
 int num_variants() { return (int)(sizeof(kVariantNames) / sizeof(kVariantNames[0])); }
@@ -1702,74 +1692,57 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
             <<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
-template <typename RecT>
-static void launch_scene_tiled(const RenderParams& P, unsigned tiles_y, hipStream_t stream) {
-    const unsigned grid = (unsigned)((P.tiles_x + 3) / 4) * tiles_y;
-    const size_t tile_bytes = 2 * (size_t)kSceneTile * 32;
-    constexpr int DEEP = deep_lds_levels<RecT>();
-    if (!needs_pool(P))
-        render_scene_tiled_kernel<MathFast, RecT, 16, kSceneTile>
-            <<<grid, 256, tile_bytes + 4 * 16 * 64 * sizeof(RecT), stream>>>(P);
-    else
-        render_scene_tiled_kernel<MathFast, RecT, DEEP, kSceneTile>
-            <<<grid, 256, tile_bytes + 4 * DEEP * 64 * sizeof(RecT), stream>>>(P);
-}
-
-static void launch_render(int variant, const RenderParams& P, unsigned grid, unsigned tiles_y,
-                          hipStream_t stream) {
+// `variant` is resolved (render_view): one of ref, fast-lds, fast-global, stamped, global-defer, primary-reuse, fp32.
+static void launch_render(int variant, const RenderParams& P, unsigned grid, hipStream_t stream) {
     const int n = P.scene.n;
-    if (variant == kVariantAuto) variant = (n <= kLdsTableMaxSpheres) ? kVariantFastLds : kVariantSceneTiled;
-    if (variant == kVariantSceneTiled) {
-        if (n <= 256) launch_scene_tiled<uint8_t>(P, tiles_y, stream);
-        else launch_scene_tiled<uint32_t>(P, tiles_y, stream);
-        return;
-    }
+    const unsigned split_grid = P.split_first + P.n_tiles * P.split;
     if (variant == kVariantFastLds && n > kLdsTableMaxSpheres) variant = kVariantFastGlobal;
-    if (variant == kVariantRef) {
-        if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
-        else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
-    } else if (variant == kVariantFastLds) {
-        if (P.split > 1) {
+    switch (variant) {
+        case kVariantRef:
+            if (n <= 256) launch_render_depth<MathRef, false, 1, uint8_t>(P, grid, stream);
+            else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
+            return;
+        case kVariantFastLds:  // (n < 8: no full chunk of 8, the instantiation without the chunk loop)
+            if (P.split > 1) {
+                if (n < 8) launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
+                else launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
+                split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+            } else if (n < 8) {
+                launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
+            } else {
+                launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
+            }
+            return;
+        case kVariantGlobalDefer:  // render_view: n < 256
+            if (P.split > 1) {
+                launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
+                split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+            } else {
+                launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
+            }
+            return;
+        case kVariantFp32: {  // validated by render_view: repaired mode, 1 <= n <= 256
+            const size_t lds = (((size_t)n * kFp32Row * sizeof(float) + 15) & ~(size_t)15) + 10 * sizeof(double);
+            render_fp32_kernel<<<grid, 64, lds, stream>>>(P);
+            return;
+        }
+        case kVariantPrimaryReuse: {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
+            const size_t lds = lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                               kFoldQueueBytes + debug_lds_pad();
             if (n < 8)
-                launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
+                render_tiles_kernel<MathFast, true, -8, uint8_t, 16, 4, true, false, true, false, true, false, true>
+                    <<<grid, 64, lds, stream>>>(P);
             else
-                launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
-            split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
-        } else if (n < 8) {  // no full chunk of 8: the instantiation without the chunk loop
-            launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
-        } else {
-            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
+                render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, false, true, false, true>
+                    <<<grid, 64, lds, stream>>>(P);
+            return;
         }
-    } else if (variant == kVariantFp32) {  // validated by render_view: repaired mode, 1 <= n <= 256
-        const size_t lds = (((size_t)n * kFp32Row * sizeof(float) + 15) & ~(size_t)15) + 10 * sizeof(double);
-        render_fp32_kernel<<<grid, 64, lds, stream>>>(P);
-    } else if (variant == kVariantPrimaryReuse) {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
-        const size_t lds = lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                           kFoldQueueBytes + debug_lds_pad();
-        if (n < 8)
-            render_tiles_kernel<MathFast, true, -8, uint8_t, 16, 4, true, false, true, false, true, false, true>
-                <<<grid, 64, lds, stream>>>(P);
-        else
-            render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, false, true, false, true>
-                <<<grid, 64, lds, stream>>>(P);
-    } else if (variant == kVariantGlobalDefer && n < 256) {
-        if (P.split > 1) {
-            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, P.split_first + P.n_tiles * P.split, stream);
-            split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
-        } else {
-            launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
-        }
-    } else if (variant == kVariantImmediateFold && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true>(P, grid, stream);
-    } else if (variant == 5 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, false, false, true>(P, grid, stream);
-    } else if (variant == 6 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, false>(P, grid, stream);
-    } else if (variant == 7 && n <= kLdsTableMaxSpheres) {
-        launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true, true>(P, grid, stream);
-    } else {
-        if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
-        else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
+        case kVariantStamped:  // render_view: n <= kLdsTableMaxSpheres
+            launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true, true>(P, grid, stream);
+            return;
+        default:  // kVariantFastGlobal: the chunked kernel with global-memory tables, any n
+            if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
+            else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
     }
 }
 
@@ -1848,7 +1821,14 @@ StreamCtx* get_ctx(int device, hipStream_t stream) {
 struct SceneCache {
     std::mutex mu;
     std::vector<std::shared_ptr<rtm_scene>> entries;  // most recently used last
-} g_scene_cache;
+};
+// a heap object that is never destroyed: its entries' deleter calls HIP, which must not happen from a static destructor
+// at process exit (the runtime may be gone by then)
+SceneCache& scene_cache() {
+    static SceneCache* c = new SceneCache;
+    return *c;
+}
+#define g_scene_cache scene_cache()
 constexpr size_t kSceneCacheEntries = 8;
 
 uint64_t hash_bytes(const void* data, size_t bytes) {  // FNV-1a over 8-byte words (+ tail bytes)
@@ -1888,7 +1868,8 @@ static int cached_scene(const rtm_sphere* sp, size_t n, int device, std::shared_
     std::lock_guard<std::mutex> lock(g_scene_cache.mu);
     auto& e = g_scene_cache.entries;
     for (size_t i = 0; i < e.size(); ++i)
-        if (e[i]->device == device && e[i]->n == n && e[i]->content_hash == h) {
+        if (e[i]->device == device && e[i]->n == n && e[i]->content_hash == h &&
+            e[i]->content.size() == n * sizeof(rtm_sphere) && std::memcmp(e[i]->content.data(), sp, n * sizeof(rtm_sphere)) == 0) {
             if (i + 1 != e.size()) std::rotate(e.begin() + (long)i, e.begin() + (long)i + 1, e.end());
             *out = e.back();
             return RTM_OK;
@@ -1897,10 +1878,8 @@ static int cached_scene(const rtm_sphere* sp, size_t n, int device, std::shared_
     const int rc = scene_build_host(*sc, sp, n, device);
     if (rc != RTM_OK) return rc;
     sc->content_hash = h;
-    if (e.size() >= kSceneCacheEntries) {
-        e.erase(e.begin());
-        RTM_HIP_CHECK(hipSetDevice(device));
-    }
+    sc->content.assign(reinterpret_cast<const unsigned char*>(sp), reinterpret_cast<const unsigned char*>(sp) + n * sizeof(rtm_sphere));
+    if (e.size() >= kSceneCacheEntries) e.erase(e.begin());  // (the deleter parks it if a render from it is still queued)
     e.push_back(sc);
     *out = sc;
     return RTM_OK;
@@ -1926,7 +1905,7 @@ int release_scratch(int device) {
         auto& e = g_scene_cache.entries;
         for (auto it = e.begin(); it != e.end();) {
             if (device < 0 || (*it)->device == device) {
-                it = e.erase(it);  // the deleter waits for the device
+                it = e.erase(it);  // parked if a render from it is still queued; reaped below, after the wait
             } else {
                 ++it;
             }
@@ -1943,6 +1922,7 @@ int release_scratch(int device) {
             ++it;
         }
     }
+    reap_scenes(true, device);  // scenes destroyed while renders from them were queued: the device is idle now
     (void)hipGetLastError();
     return RTM_OK;
 }
@@ -2001,15 +1981,7 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
 // never grows, so a grid sized for the last count seen covers the trips queued after it (blocks beyond the
 // live list exit at once), and the batch queued when the zero is finally seen is a handful of empty
 // launches.
-template <int TILE, int K, int R>
-static void launch_wf_nearest(const RenderParams& P, const WfState& S, int cur, unsigned na, hipStream_t stream) {
-    const unsigned g = (na + 256 * R - 1) / (256 * R);
-    wf_nearest_kernel<MathFast, TILE, K, R><<<g, 256, 2 * (size_t)TILE * 32, stream>>>(P, S, cur);
-}
-
-static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int scalar_scene) {
-    // (TILE, K, R) = (512 spheres per LDS tile, 4 per chunk, 1 ray per lane): profiles/r1/wf_tune.txt —
-    // smaller chunks or 2-4 rays per lane (fewer LDS reads per ray, fewer waves) were 0-50 % slower
+static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx) {
     hipStream_t stream = ctx.stream;
     WfState S;
     std::memset(&S, 0, sizeof S);
@@ -2053,7 +2025,7 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
     S.part_id = (int*)take((size_t)(kWfMaxParts - 1) * kWfPartSlots * 4);
     S.part_slots = kWfPartSlots;
     S.parts = 1;
-    if (scalar_scene >= 2 && !P.scene.geom32) {
+    if (!P.scene.geom32) {
         set_last_error("scene without rejection-test data");
         return RTM_ERR_INVALID_ARGUMENT;
     }
@@ -2086,29 +2058,14 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, int sc
         const unsigned g = (na + 255) / 256;
         // few rays against a long list: cut the list so that rays x parts fills the chip (~16 waves per SIMD's worth)
         int parts = 1;
-        if (scalar_scene == 3)
-            while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * parts * 2 <= (1ull << 20) &&
+        while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * parts * 2 <= (1ull << 20) &&
                    P.scene.n / (parts * 2) >= 2048)
                 parts *= 2;
-        static const bool x1 = [] {
-            const char* e = std::getenv("RTM_DEBUG_WF_X2");  // A/B: "1" selects the two-rays-per-lane rejection kernel
-            return !(e && e[0] == '1');
-        }();
-        const unsigned g2 = x1 ? g : (na + 511) / 512;  // blocks of the two-rays-per-lane kernel
         S.parts = parts;
-        S.part_blocks = scalar_scene == 3 ? g2 : g;
+        S.part_blocks = g;
         for (int k = 0; k < batch; ++k, ++trip) {
             RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-            if (scalar_scene == 3 && !x1)
-                wf_nearest_f32x2_kernel<MathFast, 256, 8><<<g2 * (unsigned)parts, 256, 2 * 256 * kWfCandCapX2 * sizeof(unsigned), stream>>>(P, S, cur);
-            else if (scalar_scene == 3)
-                wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
-            else if (scalar_scene == 2)
-                wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256, 0, stream>>>(P, S, cur);
-            else if (scalar_scene == 1)
-                wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256, 0, stream>>>(P, S, cur);
-            else
-                launch_wf_nearest<512, 4, 1>(P, S, cur, na, stream);
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
             wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
             cur ^= 1;
         }
@@ -2156,6 +2113,29 @@ static int take_stream_status(StreamCtx& ctx, bool wait) {
     *ctx.flag_host = 0ull;
     set_last_error(std::string("an earlier render on this stream was truncated: ") + kOverflowText);
     return RTM_ERR_UNSUPPORTED;
+}
+
+// rtm_stream_release: the (device, stream) context goes — after the stream's queued work, which may still use its buffers.
+int stream_release(int device, void* stream_v) {
+    std::shared_lock<std::shared_mutex> gate(g_gate);
+    DeviceGuard guard;
+    RTM_HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<StreamCtx> ctx;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        auto it = g_ctx.find({device, (hipStream_t)stream_v});
+        if (it == g_ctx.end()) return RTM_OK;
+        ctx = std::move(it->second);
+        g_ctx.erase(it);
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);  // a call that is enqueueing on the pair finishes first
+        rc = take_stream_status(*ctx, true);        // waits for the stream; reports an overflow nobody has seen
+        ctx->free_all();
+    }
+    reap_scenes(false);
+    return rc;
 }
 
 int stream_status(int device, void* stream_v) {
@@ -2209,6 +2189,11 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     // 16 waves per CU); global-memory tables up to 511 (the tables no longer cost occupancy); from 512
     // spheres the wavefront pipeline with its rejection test wins over the monolithic kernel
     const bool force_split = variant == kVariantSplit;
+    if (variant < 0 || variant >= num_variants() || variant_retired(variant)) {
+        set_last_error(variant >= 0 && variant < num_variants() ? std::string("variant ") + std::to_string(variant) + ": " + kVariantNames[variant]
+                                                                : std::string("no such variant"));
+        return RTM_ERR_UNSUPPORTED;
+    }
     if (variant == kVariantAuto)
         variant = n <= (size_t)kAutoLdsTableSpheres ? kVariantFastLds : n < 256 ? kVariantGlobalDefer :
                   n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
@@ -2221,6 +2206,9 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         }
         variant = kVariantRef;
     }
+    // beyond what their records / tables hold, the packed-record and the stamped kernels hand over to the global-table one
+    if ((variant == kVariantStamped && n > (size_t)kLdsTableMaxSpheres) || (variant == kVariantGlobalDefer && n >= 256))
+        variant = kVariantFastGlobal;
     if (variant == kVariantFp32 && !(n >= 1 && n <= 256 && P.mode == RTM_MODE_REPAIRED)) {
         set_last_error("variant 16 (fp32 fast row) serves repaired-mode scenes of 1..256 spheres");
         return RTM_ERR_UNSUPPORTED;
@@ -2247,9 +2235,16 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
             const size_t part = (size_t)P.n_tiles * 192, terms = (size_t)P.n_tiles * (P.total_samples - P.split_head) * 256;
             rc = scratch_acquire(ctx, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
-            if (rc != RTM_OK) return rc;
-            P.partial = split_ws;
-            P.contrib = split_ws + part;
+            if (rc == RTM_OK) {
+                P.partial = split_ws;
+                P.contrib = split_ws + part;
+            } else {  // no room for the terms: the launch runs unsplit (same image, a longer tail) instead of failing
+                (void)hipGetLastError();
+                P.split = 1;
+                P.n_tiles = grid;
+                P.split_first = 0;
+                P.split_len = P.split_head = P.total_samples;
+            }
         }
     }
     // deep-path record pool.  Kernels with an LDS record stack take a slot only for the
@@ -2269,7 +2264,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     }
 
     DevMem stamps;
-    if (opt->variant == 7) {
+    if (variant == kVariantStamped) {
         rc = stamps.alloc((size_t)grid * 4 * sizeof(unsigned long long));
         if (rc != RTM_OK) return rc;
         RTM_HIP_CHECK(hipMemset(stamps.p, 0, (size_t)grid * 4 * sizeof(unsigned long long)));
@@ -2282,15 +2277,11 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         if (rc != RTM_OK) return rc;
         RTM_HIP_CHECK(hipEventRecord(ev.a, stream));
     }
-    const bool wavefront = variant == kVariantWavefront || variant == kVariantWavefrontScalar ||
-                           variant == kVariantWavefrontReject || variant == kVariantWavefrontRejectF32;
-    if (wavefront) {
-        // scalar stream + single-precision rejection test (profiles/r1/wf_tune.txt); 8, 10, 11 stay as A/B twins
-        rc = run_wavefront(P, rows, ctx, variant == kVariantWavefront ? 0 : variant == kVariantWavefrontScalar ? 1 :
-                                         variant == kVariantWavefrontReject ? 2 : 3);
+    if (variant == kVariantWavefrontRejectF32) {
+        rc = run_wavefront(P, rows, ctx);
         if (rc != RTM_OK) return rc;
     } else {
-        launch_render(variant, P, grid, tiles_y, stream);
+        launch_render(variant, P, grid, stream);
     }
     RTM_HIP_CHECK(hipGetLastError());
     if (stamps.p) {  // diagnostic variant: print the per-wave segment shares
@@ -2343,9 +2334,12 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
         return RTM_ERR_INVALID_ARGUMENT;
     }
     std::shared_lock<std::shared_mutex> gate(g_gate);
-    return render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                      scene->has_planes ? scene->plane.as<double>() : nullptr),
-                       scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
+    reap_scenes(false);
+    rc = render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
+                                    scene->has_planes ? scene->plane.as<double>() : nullptr),
+                     scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
+    note_scene_use(scene, (hipStream_t)stream_v);  // also after a failure: part of the work may have been queued
+    return rc;
 }
 
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on_device,
@@ -2360,8 +2354,10 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_scene(sp, n, opt->device, &sc);
         if (rc != RTM_OK) return rc;
-        return render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n), n, opt,
-                           out64, out32, out8, stream, stats);
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n), n, opt,
+                         out64, out32, out8, stream, stats);
+        note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
+        return rc;
     }
     // device-resident sphere array: flattened on the stream into stream-ordered temporaries, which are
     // released (hipFreeAsync) behind the render's launches
@@ -2625,11 +2621,12 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
     return RTM_OK;
 }
 
-// Test hook: the large-scene nearest-hit kernels on caller-given rays.  kind 0: LDS tiles, 1: scalar
-// stream, 2: scalar stream + rejection test.  Host buffers; out_id/out_t per ray.
+// Test hook: nearest hit for caller-given rays.  kind 1: the reference's loop, nothing in front of it (the literal
+// per-sphere loop with the compiler's math, one lane per ray); kind 3: the large-scene kernel with its packed-fp32
+// rejection test and candidate lists.  Host buffers; out_id/out_t per ray.
 int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
                      int32_t* out_id, double* out_t) {
-    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || kind < 0 || kind > 4 || n_rays > 0x7FFFFFFFull)
+    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || (kind != 1 && kind != 3) || n_rays > 0x7FFFFFFFull)
         return RTM_ERR_INVALID_ARGUMENT;
     int device = 0;
     RTM_HIP_CHECK(hipGetDevice(&device));
@@ -2675,7 +2672,7 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     const unsigned counts[2] = {(unsigned)N, 0u};
     RTM_HIP_CHECK(hipMemcpy(S.n_active, counts, sizeof counts, hipMemcpyHostToDevice));
     const unsigned g = (unsigned)((N + 255) / 256);
-    if (kind >= 2) {
+    if (kind == 3) {
         RTM_HIP_CHECK(hipMemset(aux, 0, 32));
         float4* g32 = reinterpret_cast<float4*>(aux + 4 + n_pad);
         wf_scene_scale_kernel<<<(n_pad + 255) / 256, 256>>>(P.scene.geom, P.scene.n, reinterpret_cast<long long*>(aux + 2));
@@ -2685,16 +2682,9 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
         P.scene.wprime = aux + 4;
         P.scene.geom32 = g32;
         P.scene.geom32s = g32 + n_pad;
-        if (kind == 4)  // two rays per lane (A/B twin, RTM_DEBUG_WF_X2=1)
-            wf_nearest_f32x2_kernel<MathFast, 256, 8><<<(unsigned)((N + 511) / 512), 256, 2 * 256 * kWfCandCapX2 * sizeof(unsigned)>>>(P, S, 0);
-        else if (kind == 3)  // the default: two spheres per packed instruction
-            wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 256 * kWfCandCap * sizeof(unsigned)>>>(P, S, 0);
-        else
-            wf_nearest_scalar_kernel<MathFast, 4, 256, true><<<g, 256>>>(P, S, 0);
-    } else if (kind == 1) {
-        wf_nearest_scalar_kernel<MathFast, 4, 256, false><<<g, 256>>>(P, S, 0);
+        wf_nearest_f32_kernel<MathFast, 256, 8><<<g, 256, 256 * kWfCandCap * sizeof(unsigned)>>>(P, S, 0);
     } else {
-        launch_wf_nearest<512, 4, 1>(P, S, 0, (unsigned)N, nullptr);
+        nearest_probe_kernel<<<g, 256>>>(P.scene, S.org, S.dir, (unsigned)N, S.hit_id, S.hit_t);
     }
     RTM_HIP_CHECK(hipGetLastError());
     RTM_HIP_CHECK(hipDeviceSynchronize());

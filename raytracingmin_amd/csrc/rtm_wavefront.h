@@ -4,13 +4,14 @@
 // With 10^5 spheres a ray cast is ~2 M instructions of brute-force intersection against ~500 of
 // shading, so the two are split into kernels with their own register budgets:
 //   nearest hit  one lane per ACTIVE pixel (compacted index list), nothing live but the ray and the
-//                running nearest hit.  Four interchangeable kernels, oldest first:
-//                  wf_nearest_kernel                   sphere list streamed HBM/L2 -> LDS in tiles
-//                  wf_nearest_scalar_kernel<.., false> list read through the scalar cache into SGPRs
-//                  wf_nearest_scalar_kernel<.., true>  + conservative 8-FMA fp64 rejection test
-//                  wf_nearest_f32_kernel (default)     + the rejection test in packed fp32
+//                running nearest hit: wf_nearest_f32_kernel — the sphere list read through the scalar
+//                cache into SGPRs, a conservative rejection test in packed fp32 in front of the
+//                reference's arithmetic, per-lane candidate lists for what it cannot reject.  (Its three
+//                predecessors — LDS tiles, scalar stream without a test, fp64 test — and the two-rays-per-
+//                instruction twin were A/B-ed in rounds 1-2 and retired from the product:
+//                profiles/r3/retired_variants.patch)
 //                Every ray still meets every sphere, in index order, and every possible hit is
-//                decided by the reference's own arithmetic (sphere_chunk_g).
+//                decided by the reference's own arithmetic.
 //   wf_shade     the rest of PathTracing (src/Renderer.cpp:75-117), the back-to-front fold, the
 //                per-sample accumulate and path regeneration, with the per-pixel state in HBM (SoA),
 //                then wave-ballot/prefix COMPACTION of the pixels that still have samples into the
@@ -50,7 +51,6 @@ struct WfState {
     double* part_t;
     int* part_id;
 };
-constexpr int kWfCandCapX2 = 12;             // the same per RAY of wf_nearest_f32x2_kernel (two rays per lane: 24 KB per block)
 constexpr int kWfCandCap = 16;               // candidate slots per lane of wf_nearest_f32_kernel (LDS: 4 B x BLOCK each)
 constexpr unsigned kWfPartSlots = 1u << 19;  // the split is used only while the active list is this short
 constexpr int kWfMaxParts = 8;
@@ -83,90 +83,6 @@ __global__ __launch_bounds__(256) void wf_init_kernel(const RenderParams P, cons
     S.left[p] = P.S;
     S.depth[p] = 0;
     S.active[0][p] = p;
-}
-
-// Nearest hit for the active pixels (src/Renderer.cpp:58-73 + src/SettingData.cpp:197-226).
-// R rays per lane: the geometry of a chunk is read from LDS once and tested against R rays, which
-// divides the broadcast LDS reads per ray by R.
-template <class M, int TILE, int K, int R>
-__global__ __launch_bounds__(256) void wf_nearest_kernel(const RenderParams P, const WfState S, const int cur) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double2* tile_buf = reinterpret_cast<double2*>(lds_raw);  // 2 x TILE x 2 double2
-    const unsigned na = S.n_active[cur];
-    if (blockIdx.x * (256u * R) >= na) return;  // whole block beyond the active list
-    const int tid = threadIdx.x;
-    const unsigned N = S.npix;
-    unsigned p[R];
-    bool live[R];
-    D3 org[R], dir[R];
-    double dis[R];
-    int id[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned i = blockIdx.x * (256u * R) + r * 256u + tid;
-        live[r] = i < na;
-        p[r] = S.active[cur][live[r] ? i : na - 1];
-        org[r] = d3(S.org[p[r]], S.org[N + p[r]], S.org[2 * N + p[r]]);
-        dir[r] = d3(S.dir[p[r]], S.dir[N + p[r]], S.dir[2 * N + p[r]]);
-        dis[r] = DBL_MAX;
-        id[r] = -1;
-    }
-
-    constexpr int CHUNKS = TILE * 2 / 256;
-    const int n = P.scene.n;
-    const int n_tiles = (n + TILE - 1) / TILE;
-    const double2* gsrc = reinterpret_cast<const double2*>(P.scene.geom);
-    const int n_chunks = n * 2;
-#pragma unroll
-    for (int k = 0; k < CHUNKS; ++k) {
-        const int c = k * 256 + tid;
-        tile_buf[c] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
-    }
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        double2 pre[CHUNKS];
-        const bool more = (t + 1 < n_tiles);
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < CHUNKS; ++k) {
-                const int c = (t + 1) * TILE * 2 + k * 256 + tid;
-                pre[k] = (c < n_chunks) ? gsrc[c] : double2{0.0, 0.0};
-            }
-        }
-        const int base = t * TILE;
-        const int cnt = (n - base < TILE) ? (n - base) : TILE;
-        const double2* curt = tile_buf + (t & 1) * TILE * 2;
-        int j = 0;
-        for (; j + K <= cnt; j += K) {
-            double4 g[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {  // same LDS address in every lane: broadcast
-                const double2 a = curt[2 * (j + k)], b = curt[2 * (j + k) + 1];
-                g[k] = double4{a.x, a.y, b.x, b.y};
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) sphere_chunk_g<M, K, true>(g, base + j, org[r], dir[r], dis[r], id[r]);
-        }
-        for (; j < cnt; ++j) {
-            double4 g[1];
-            const double2 a = curt[2 * j], b = curt[2 * j + 1];
-            g[0] = double4{a.x, a.y, b.x, b.y};
-#pragma unroll
-            for (int r = 0; r < R; ++r) sphere_chunk_g<M, 1, true>(g, base + j, org[r], dir[r], dis[r], id[r]);
-        }
-        if (more) {
-            double2* nxt = tile_buf + ((t + 1) & 1) * TILE * 2;
-#pragma unroll
-            for (int k = 0; k < CHUNKS; ++k) nxt[k * 256 + tid] = pre[k];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (live[r]) {
-            S.hit_id[p[r]] = id[r];
-            S.hit_t[p[r]] = dis[r];
-        }
 }
 
 // Auxiliary per-sphere data for the rejection tests.  aux = [R2][r2max][exponent sum][count] then
@@ -226,116 +142,23 @@ __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __rest
     if (g.w >= 0.0) atomicMax(bounds + 1, (unsigned long long)__double_as_longlong(g.w));
 }
 
-// The nearest-hit pass with the sphere list read through the SCALAR cache instead of LDS tiles, and a
-// conservative REJECTION TEST in front of the reference's arithmetic.
-//  * The walk is wave-uniform, so a chunk of K spheres is a few s_loads into SGPRs (two SGPR buffers,
-//    one in flight while the other is tested) and the VALU takes its sphere operands straight from
-//    SGPRs: no LDS round trip, no tile staging, no barriers.  All waves stream the same list, so the
-//    scalar caches and L2 absorb the re-reads (measured: identical speed with an always-hit list).
-//  * 99.99 % of (ray, sphere) pairs of such a scene have a negative discriminant and are only ever
-//    REJECTED; for that decision the reference's 16 non-fused operations are not needed.  With
-//    P = c - o:  D4 = (P.d)^2 - P.P + r2 = (c.d - o.d)^2 + (r2 - c.c) + 2 c.o - o.o, which is 8 FMAs per
-//    sphere from (cx, cy, cz, w' = r2 - c.c) and per-ray constants.  Both this value and the
-//    reference's are within  27 u (1 + d.d)(max c.c + o.o + max r2)  of the exact discriminant
-//    (u = 2^-53; standard dot-product bounds), so a sphere whose fused value is below
-//    -margin, margin = 2048 u (...), has a negative reference discriminant and cannot be hit.  Any
-//    other chunk runs the reference's arithmetic (sphere_chunk_g), which alone decides hits: the
-//    image cannot change.  NaN / infinite operands make the margin NaN / infinite; such rays accept
-//    nothing in the reference either (every comparison with their t is false).
-template <class M, int K, int BLOCK, bool REJECT>
-__global__ __launch_bounds__(BLOCK) void wf_nearest_scalar_kernel(const RenderParams P, const WfState S, const int cur) {
-    static_assert(K == 4, "one 32-byte w' load per chunk");
-    const unsigned na = S.n_active[cur];
-    if (blockIdx.x * (unsigned)BLOCK >= na) return;
-    const unsigned i = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
-    const bool live = i < na;
-    const unsigned N = S.npix;
-    const unsigned p = S.active[cur][live ? i : na - 1];
-    const D3 org = d3(S.org[p], S.org[N + p], S.org[2 * N + p]);
-    const D3 dir = d3(S.dir[p], S.dir[N + p], S.dir[2 * N + p]);
-    double dis = DBL_MAX;
-    int id = -1;
-    const int n = P.scene.n;
-
-    // per-ray constants of the rejection test
-    const double od = __builtin_fma(org.z, dir.z, __builtin_fma(org.y, dir.y, org.x * dir.x));
-    const double oo = __builtin_fma(org.z, org.z, __builtin_fma(org.y, org.y, org.x * org.x));
-    const double dd = __builtin_fma(dir.z, dir.z, __builtin_fma(dir.y, dir.y, dir.x * dir.x));
-    const D3 o2 = d3(org.x + org.x, org.y + org.y, org.z + org.z);
-    double neg_margin = 0.0;
-    if constexpr (REJECT) {
-        typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
-        ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
-        const double mag = (1.0 + dd) * (bnd[0] + oo + bnd[1]);  // bounds every intermediate of the test
-        neg_margin = (mag < 0x1p1000) ? -(0x1p-42 * mag) : -HUGE_VAL;   // near overflow / non-finite: reject nothing
-    }
-    auto load_w = [&](int j, double (&w)[K]) {
-        typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
-        ConstF64Ptr q = (ConstF64Ptr)(unsigned long long)(P.scene.wprime + j);
-#pragma unroll
-        for (int k = 0; k < K; ++k) w[k] = q[k];
-    };
-    auto test = [&](const double4 (&g)[K], const double (&w)[K], int j) {
-        if constexpr (REJECT) {
-            double top = -HUGE_VAL;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const double bq = __builtin_fma(g[k].z, dir.z, __builtin_fma(g[k].y, dir.y, __builtin_fma(g[k].x, dir.x, -od)));
-                const double tq = w[k] + __builtin_fma(g[k].z, o2.z, __builtin_fma(g[k].y, o2.y, __builtin_fma(g[k].x, o2.x, -oo)));
-                top = __builtin_fmax(top, __builtin_fma(bq, bq, tq));
-            }
-            if (__builtin_amdgcn_ballot_w64(top >= neg_margin) == 0) return;
-        }
-        sphere_chunk_g<M, K, true>(g, j, org, dir, dis, id);
-    };
-
-    // two chunk buffers (A, B) in SGPRs: while one is tested the other is in flight.  Scalar loads
-    // return out of order, so the only wait is "all of them": each buffer is requested right after
-    // the wait that delivered the other one and has a whole chunk's arithmetic to arrive.
-    const int n_pairs = n / (2 * K);
-    const int n_full = n_pairs * 2 * K;
-    double4 a[K], b[K];
-    double wa[K], wb[K];
-    if (n_pairs > 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) a[k] = load_geom_uniform(P.scene.geom, k);
-        if constexpr (REJECT) load_w(0, wa);
-    }
-    for (int j = 0; j < n_full; j += 2 * K) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < K; ++k) b[k] = load_geom_uniform(P.scene.geom, j + K + k);
-        if constexpr (REJECT) load_w(j + K, wb);
-        __builtin_amdgcn_sched_barrier(0);
-        test(a, wa, j);
-        const int jn = (j + 2 * K < n_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < K; ++k) a[k] = load_geom_uniform(P.scene.geom, jn + k);
-        if constexpr (REJECT) load_w(jn, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        test(b, wb, j + K);
-    }
-    for (int j = n_full; j < n; ++j) {
-        double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
-        sphere_chunk_g<M, 1, true>(g1, j, org, dir, dis, id);
-    }
-    if (live) {
-        S.hit_id[p] = id;
-        S.hit_t[p] = dis;
-    }
-}
-
-// The rejection test in SINGLE precision (twice the issue rate), in front of the reference arithmetic.
+// The nearest-hit pass of the large-scene pipeline.
+//  * The walk over the sphere list is wave-uniform, so a chunk of K spheres is one or two s_loads into SGPRs
+//    (two SGPR buffers, one in flight while the other is tested) and the VALU takes its sphere operands
+//    straight from SGPRs: no LDS round trip, no tile staging, no barriers.  All waves stream the same list,
+//    so the scalar caches and L2 absorb the re-reads.
+//  * 99.99 % of (ray, sphere) pairs of such a scene have a negative discriminant and are only ever REJECTED;
+//    for that decision the reference's 16 non-fused operations are not needed, only a guarantee.  With
+//    P = c - o:  D4 = (P.d)^2 - P.P + r2 = (c.d - o.d)^2 + (r2 - c.c) + 2 c.o - o.o.  Both an FMA evaluation of
+//    that identity in fp64 and the reference's own are within  27 u64 (1 + d.d)(max c.c + o.o + max r2)  of the
+//    exact discriminant (standard dot-product bounds): the "fp64 margin" below.
+// The test runs in SINGLE precision (packed: two spheres per instruction), in front of the reference arithmetic.
 // Same identity, arranged so that the per-sphere data is (cx, cy, cz, w') as floats:
 //   D4 = (c.d)^2 + c.e + w' + k,   e = 2o - 2(o.d)d,  k = (o.d)^2 - o.o   (per-ray, computed in fp64)
 // = 1 mul + 6 fma + 1 add in fp32.  With u = 2^-24, rounding every input to float and every operation
 // once gives (Higham's gamma_n bounds; sum |c_i||x_i| <= R |x|_1, R^2 = max c.c):
 //   |D4_f32 - D4| <= u [ 11.7 R^2 d.d + 7.2 R |e|_1 + 6.1 |k| + 6.1 (R^2 + max r2) ]
-// plus underflow (<= 17 x 2^-126 x max(1, |d|, |e|, 2R|d|)) and the fp64-level terms of
-// wf_nearest_scalar_kernel.  The kernel uses 16 u (...) + 2^-110 (1 + d.d + |e|_1 + R^2) + the fp64
+// plus underflow (<= 17 x 2^-126 x max(1, |d|, |e|, 2R|d|)) and the fp64 margin above.  The kernel uses 16 u (...) + 2^-110 (1 + d.d + |e|_1 + R^2) + the fp64
 // margin, rounded up; a chunk none of whose spheres reaches -margin in any lane is skipped, and in any
 // other chunk the spheres some lane could not reject get the reference arithmetic, in index order.
 // When the magnitude sum is >= 2^100 (a product could overflow a float) or not finite, the margin is
@@ -507,233 +330,6 @@ __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParam
         } else {
             S.part_id[(size_t)(part - 1u) * S.part_slots + i] = id;
             S.part_t[(size_t)(part - 1u) * S.part_slots + i] = dis;
-        }
-    }
-}
-
-// ---- two rays per lane -------------------------------------------------------------------------------------------
-// The packed instructions of wf_nearest_f32_kernel carry two SPHERES for one ray, so every sphere operand is an SGPR
-// pair and the addend w' has to be moved into a vector register first (a VOP3P instruction reads ONE scalar operand):
-// 8 instructions per sphere pair, 38 per chunk of 8 with the maximum and the compare.  Here they carry two RAYS for
-// one sphere: the sphere's (cx, cy) and (cz, w') are two SGPR pairs, each instruction broadcasts one HALF of one pair to
-// both rays through op_sel, and "cz * ez + w'" reads both of its scalar operands from the SAME pair — 7 instructions
-// per sphere and ray pair, no moves: 66 per chunk of 8 spheres x 128 rays instead of 76.  Same arithmetic per (ray,
-// sphere) as before up to the order of the three products of c.e (the margin bounds every partial sum by the same
-// quantity), same candidate lists, same exact settlement.
-typedef float wf_f2 __attribute__((ext_vector_type(2)));
-// d = s.x * v + c / d = s.y * v + c / d = s.x * v + s.y / d = s.x * v   (s: a sphere's SGPR pair, v and c: the two rays)
-__device__ __forceinline__ wf_f2 pk_fma_sx(unsigned long long s, wf_f2 v, wf_f2 c) {
-    wf_f2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(s), "v"(v), "v"(c));
-    return d;
-}
-__device__ __forceinline__ wf_f2 pk_fma_sy(unsigned long long s, wf_f2 v, wf_f2 c) {
-    wf_f2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(s), "v"(v), "v"(c));
-    return d;
-}
-__device__ __forceinline__ wf_f2 pk_fma_sx_sy(unsigned long long s, wf_f2 v) {
-    wf_f2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "s"(s), "v"(v));
-    return d;
-}
-__device__ __forceinline__ wf_f2 pk_mul_sx(unsigned long long s, wf_f2 v) {
-    wf_f2 d;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(s), "v"(v));
-    return d;
-}
-
-template <class M, int BLOCK, int K>
-__global__ __launch_bounds__(BLOCK) void wf_nearest_f32x2_kernel(const RenderParams P, const WfState S, const int cur) {
-    static_assert(K == 8, "two 64-byte scalar loads per chunk");
-    const unsigned na = S.n_active[cur];
-    const int parts = S.parts > 1 ? S.parts : 1;
-    const unsigned part = parts > 1 ? blockIdx.x / S.part_blocks : 0u;       // wave-uniform
-    const unsigned ray_block = parts > 1 ? blockIdx.x % S.part_blocks : blockIdx.x;
-    if (ray_block * (unsigned)(2 * BLOCK) >= na) return;
-    const unsigned N = S.npix;
-    const int n = P.scene.n;
-    typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
-    typedef const __attribute__((address_space(4))) unsigned long long* ConstU64Ptr;
-    ConstF64Ptr bnd = (ConstF64Ptr)(unsigned long long)P.scene.bounds;
-    const double R2 = bnd[0], r2max = bnd[1];
-    const double R = __builtin_sqrt(R2) * (1.0 + 0x1p-40);
-
-    // ray h of this lane: slot i_h of the active list
-    struct Ray {  // (origin and direction are re-read from the ray arrays where the exact test needs them)
-        double dis;
-        int id, cnt;
-        unsigned i, p;
-        bool live;
-    } ray[2];
-    float thr[2], fd[2][3], fe[2][3];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        Ray& r = ray[h];
-        r.i = ray_block * (unsigned)(2 * BLOCK) + (unsigned)h * BLOCK + threadIdx.x;
-        r.live = r.i < na;
-        r.p = S.active[cur][r.live ? r.i : na - 1];
-        r.dis = DBL_MAX;
-        r.id = -1;
-        r.cnt = 0;
-        const D3 org = d3(S.org[r.p], S.org[N + r.p], S.org[2 * N + r.p]);
-        const D3 dir = d3(S.dir[r.p], S.dir[N + r.p], S.dir[2 * N + r.p]);
-        // the per-ray constants of the rejection test: exactly wf_nearest_f32_kernel's
-        const double od = __builtin_fma(org.z, dir.z, __builtin_fma(org.y, dir.y, org.x * dir.x));
-        const double oo = __builtin_fma(org.z, org.z, __builtin_fma(org.y, org.y, org.x * org.x));
-        const double dd = __builtin_fma(dir.z, dir.z, __builtin_fma(dir.y, dir.y, dir.x * dir.x));
-        const double od2 = od + od;
-        const D3 e = d3(__builtin_fma(-od2, dir.x, org.x + org.x), __builtin_fma(-od2, dir.y, org.y + org.y),
-                        __builtin_fma(-od2, dir.z, org.z + org.z));
-        const double kq = __builtin_fma(od, od, -oo);
-        const double e1 = __builtin_fabs(e.x) + __builtin_fabs(e.y) + __builtin_fabs(e.z);
-        const double m64 = 0x1p-42 * ((1.0 + dd) * (R2 + oo + r2max));
-        const double mag = R2 * dd + R * e1 + __builtin_fabs(kq) + R2 + r2max;
-        const double m32 = 0x1p-24 * (12.0 * (R2 * dd) + 7.0 * (R * e1) + 6.0 * (R2 + r2max)) + 0x1p-110 * (1.0 + dd + e1 + R2);
-        float t = -HUGE_VALF;
-        if (mag < 0x1p100) {
-            const double thr64 = -((m32 + m64 + 0x1p-23 * __builtin_fabs(kq)) * (1.0 + 0x1p-20)) - kq;
-            t = (float)thr64;
-            if ((double)t > thr64) t = __uint_as_float(t > 0.f ? __float_as_uint(t) - 1u :
-                                                       t < 0.f ? __float_as_uint(t) + 1u : 0x80000001u);  // next float below
-        }
-        thr[h] = t;
-        fd[h][0] = (float)dir.x; fd[h][1] = (float)dir.y; fd[h][2] = (float)dir.z;
-        fe[h][0] = (float)e.x; fe[h][1] = (float)e.y; fe[h][2] = (float)e.z;
-    }
-    const wf_f2 dx2 = wf_f2{fd[0][0], fd[1][0]}, dy2 = wf_f2{fd[0][1], fd[1][1]}, dz2 = wf_f2{fd[0][2], fd[1][2]};
-    const wf_f2 ex2 = wf_f2{fe[0][0], fe[1][0]}, ey2 = wf_f2{fe[0][1], fe[1][1]}, ez2 = wf_f2{fe[0][2], fe[1][2]};
-
-    // per-ray candidate lists in LDS, [ray half][slot][thread]
-    extern __shared__ unsigned cand[];
-    auto drain = [&](int h) {
-        Ray& r = ray[h];
-        if (__builtin_amdgcn_ballot_w64(r.cnt > 0) == 0) return;
-        unsigned* list = cand + h * (kWfCandCapX2 * BLOCK);
-        unsigned pp = r.p;
-        asm volatile("" : "+v"(pp));  // the loads stay HERE: hoisted out of the sweep they would pin 24 registers
-        const D3 org = d3(S.org[pp], S.org[N + pp], S.org[2 * N + pp]);
-        const D3 dir = d3(S.dir[pp], S.dir[N + pp], S.dir[2 * N + pp]);
-        for (int e = 0; __builtin_amdgcn_ballot_w64(e < r.cnt) != 0; ++e) {
-            if (e < r.cnt) {
-                const int jj = (int)list[e * BLOCK + threadIdx.x];
-                const double4 g = P.scene.geom[jj];
-                const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
-                const double b = dot(p_o, dir);                            // :199
-                const double D4 = b * b - dot(p_o, p_o) + g.w;                    // :200
-                const double sq = M::sqrt64(D4);                                  // :205 (D4 < 0: NaN, nothing is accepted)
-                const double t1 = b - sq, t2 = b + sq;
-                const double t = (t1 > 0.001) ? t1 : t2;
-                const bool accept = (t < r.dis) && !(t < (double)1e-5f);
-                r.dis = accept ? t : r.dis;
-                r.id = accept ? jj : r.id;
-            }
-        }
-        r.cnt = 0;
-    };
-    struct Chunk {
-        unsigned long long xy[K], zw[K];  // per sphere: (cx, cy) and (cz, w') as SGPR pairs
-    };
-    auto load32 = [&](int j, Chunk& c) {
-        ConstU64Ptr q = (ConstU64Ptr)(unsigned long long)(reinterpret_cast<const unsigned long long*>(P.scene.geom32s) + (size_t)j * 2);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            c.xy[k] = q[2 * k];
-            c.zw[k] = q[2 * k + 1];
-        }
-    };
-    auto test = [&](const Chunk& c, int j) {
-        wf_f2 tq[K];
-        // two spheres at a time, stage by stage: four independent chains, so that no instruction needs the result of the
-        // one before it (a dependent packed instruction costs a wait state)
-#pragma unroll
-        for (int k = 0; k < K; k += 2) {
-            wf_f2 u0 = pk_mul_sx(c.xy[k], dx2);
-            wf_f2 v0 = pk_fma_sx_sy(c.zw[k], ez2);
-            wf_f2 u1 = pk_mul_sx(c.xy[k + 1], dx2);
-            wf_f2 v1 = pk_fma_sx_sy(c.zw[k + 1], ez2);
-            u0 = pk_fma_sy(c.xy[k], dy2, u0);
-            v0 = pk_fma_sx(c.xy[k], ex2, v0);
-            u1 = pk_fma_sy(c.xy[k + 1], dy2, u1);
-            v1 = pk_fma_sx(c.xy[k + 1], ex2, v1);
-            u0 = pk_fma_sx(c.zw[k], dz2, u0);
-            v0 = pk_fma_sy(c.xy[k], ey2, v0);
-            u1 = pk_fma_sx(c.zw[k + 1], dz2, u1);
-            v1 = pk_fma_sy(c.xy[k + 1], ey2, v1);
-            tq[k] = __builtin_elementwise_fma(u0, u0, v0);
-            tq[k + 1] = __builtin_elementwise_fma(u1, u1, v1);
-        }
-        float top0 = tq[0].x, top1 = tq[0].y;
-#pragma unroll
-        for (int k = 1; k < K; ++k) {  // v_max_f32 / v_max3_f32 skip NaN operands
-            top0 = __builtin_fmaxf(top0, tq[k].x);
-            top1 = __builtin_fmaxf(top1, tq[k].y);
-        }
-        const unsigned long long any0 = __builtin_amdgcn_ballot_w64(top0 >= thr[0]);
-        const unsigned long long any1 = __builtin_amdgcn_ballot_w64(top1 >= thr[1]);
-        if ((any0 | any1) == 0ull) return;
-        // rare: a sphere some ray could not reject goes to that ray's list (index order: strict < keeps the lowest on
-        // ties); only the half that has such a ray is looked through
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if ((h ? any1 : any0) == 0ull) continue;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float t = h ? tq[k].y : tq[k].x;
-                const bool pass = !(t < thr[h]);
-                if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-                if (pass) {
-                    cand[h * (kWfCandCapX2 * BLOCK) + ray[h].cnt * BLOCK + threadIdx.x] = (unsigned)(j + k);
-                    ++ray[h].cnt;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(ray[h].cnt > kWfCandCapX2 - K) != 0) drain(h);  // the next chunk might not fit
-        }
-    };
-
-    // this block's range of the sphere list: all of it, or part `part` of `parts` (cut on chunk-pair boundaries)
-    const int n_pairs_all = n / (2 * K);
-    const int pairs_per = (n_pairs_all + parts - 1) / parts;
-    const int j_begin = (int)part * pairs_per * 2 * K;
-    const int j_end_full = ((int)part + 1 == parts) ? n_pairs_all * 2 * K
-                                                   : (((int)part + 1) * pairs_per < n_pairs_all ? ((int)part + 1) * pairs_per
-                                                                                              : n_pairs_all) * 2 * K;
-    Chunk a, b;
-    if (j_begin < j_end_full) load32(j_begin, a);
-    for (int j = j_begin; j < j_end_full; j += 2 * K) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): A has arrived
-        __builtin_amdgcn_sched_barrier(0);
-        load32(j + K, b);
-        __builtin_amdgcn_sched_barrier(0);
-        test(a, j);
-        const int jn = (j + 2 * K < j_end_full) ? j + 2 * K : j;  // the last trip re-reads its own chunk
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // B has arrived
-        __builtin_amdgcn_sched_barrier(0);
-        load32(jn, a);
-        __builtin_amdgcn_sched_barrier(0);
-        test(b, j + K);
-    }
-    drain(0);
-    drain(1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        Ray& r = ray[h];
-        if ((int)part + 1 == parts && n_pairs_all * 2 * K < n) {  // the spheres after the last full chunk pair: the last part's
-            const D3 org = d3(S.org[r.p], S.org[N + r.p], S.org[2 * N + r.p]);
-            const D3 dir = d3(S.dir[r.p], S.dir[N + r.p], S.dir[2 * N + r.p]);
-            for (int j = n_pairs_all * 2 * K; j < n; ++j) {
-                double4 g1[1] = {load_geom_uniform(P.scene.geom, j)};
-                sphere_chunk_g<M, 1, true>(g1, j, org, dir, r.dis, r.id);
-            }
-        }
-        if (r.live) {
-            if (part == 0u) {
-                S.hit_id[r.p] = r.id;
-                S.hit_t[r.p] = r.dis;
-            } else {
-                S.part_id[(size_t)(part - 1u) * S.part_slots + r.i] = r.id;
-                S.part_t[(size_t)(part - 1u) * S.part_slots + r.i] = r.dis;
-            }
         }
     }
 }

@@ -64,6 +64,9 @@ class Renderer:
             self._scene = None
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():  # interpreter shutdown: the HIP runtime may be gone already; the process's memory goes with it
+            return
         try:
             self.invalidate()
         except Exception:

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"{n} declared in include/rtm.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().rtm_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().rtm_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_exported_symbols_are_exactly_the_two_headers():

@@ -37,7 +37,8 @@ def _variants(rtm, data, max_bounces):
     """Kernel variants that serve this scene: all of them, except that the labelled primary-hit-reuse row
     (variant 15) is built for scenes of 1..24 spheres with a depth cap of at most 8."""
     n = len(data.object)
-    return [v for v in range(rtm.lib().rtm_num_variants())
+    live = [v for v in range(rtm.lib().rtm_num_variants()) if not rtm.lib().rtm_variant_name(v).startswith(b"retired")]
+    return [v for v in live
             if v != 16 and (v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8))]  # 16: the fp32 row, not a parity path
 
 
@@ -158,11 +159,11 @@ def _wf_nearest(rtm, kind, sph, n, org, d):
 
 
 def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
-    """wf_nearest_scalar_kernel<REJECT> drops a sphere when a fused 8-FMA discriminant is below
+    """wf_nearest_f32_kernel drops a sphere when a packed-fp32 evaluation of its discriminant is below
     -margin.  Rays aimed at the silhouettes of spheres, with the true discriminant swept through zero
     from 1e-6 down to rounding noise on both sides, plus grazing/tangent, inside-the-sphere, far-away
-    and non-finite rays, must get the id and distance of the kernels that only use the reference's
-    arithmetic — and of the oracle."""
+    and non-finite rays, must get the id and distance of the reference's loop with nothing in front of it
+    (rtm_debug_wf_nearest kind 1) — and of the oracle."""
     from raytracingmin_amd import _lib
     rng = np.random.default_rng(77)
     n = 1000
@@ -194,7 +195,7 @@ def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
         rays_d.append(np.array(d, dtype=np.float64))
     rays_o, rays_d = np.array(rays_o), np.array(rays_d)
     ref_id, ref_t = _wf_nearest(rtm, 1, arr, n, rays_o, rays_d)
-    for kind in (0, 2, 3, 4):  # 3: two spheres per packed instruction (default), 4: two rays (A/B twin)
+    for kind in (3,):  # the large-scene kernel: packed-fp32 rejection test + candidate lists
         ids, t = _wf_nearest(rtm, kind, arr, n, rays_o, rays_d)
         assert np.array_equal(ids, ref_id), kind
         assert np.array_equal(t.view(np.uint64), ref_t.view(np.uint64)), kind
@@ -211,7 +212,7 @@ def test_large_scene_rejection_test_never_rejects_a_hit(rtm, oracle):
             big[i].radius = min(float(r[i]) * scale, 3.0e38)
         o_big = rays_o[:4000] * scale
         want_id, want_t = _wf_nearest(rtm, 1, big, n, o_big, rays_d[:4000])
-        for kind in (2, 3, 4):
+        for kind in (3,):
             ids, t = _wf_nearest(rtm, kind, big, n, o_big, rays_d[:4000])
             assert np.array_equal(ids, want_id) and np.array_equal(t.view(np.uint64), want_t.view(np.uint64)), (scale, kind)
     oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
@@ -682,7 +683,7 @@ def test_interleaved_bands_reassemble_the_frame(rtm, oracle, scene, w, h, n_big)
     else:
         data = rtm.LoadData(oracle.scene_path(scene)).data
         data.width, data.height, data.samples, data.superSamples = w, h, 4, 2
-    for variant in (0, 1, 4, 8, 9):
+    for variant in (0, 1, 3, 12, 9):
         full, st_full = _gpu_image(rtm, data, "repaired", 8, 3, want=("f64", "u8"), variant=variant)
         for lo, hi, world in ((0, h, 3), (8, h - 3, 2), (0, h, 8)):
             got = np.full_like(full["f64"], np.nan)
@@ -729,14 +730,14 @@ def test_record_packing_boundary(rtm, oracle, n):
     # pull the camera close so that high-index spheres are hit, too
     ost, oarr, _ = _oracle_view(oracle, data)
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=21, height=32))
-    for v in (0, 1, 2, 9, 13, 14):
+    for v in (0, 1, 2, 9, 3, 14):
         out, stats = _gpu_image(rtm, data, "repaired", 8, 21, want=("f64",), variant=v)
         assert np.array_equal(out["f64"], ref), (n, v)
         assert stats["casts"] == cnt["casts"]
     assert ref.any()
     # any depth: records packed by position, deep levels in the pooled stack
     ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=21, height=32))
-    for v in (0, 2, 9, 14, 13):
+    for v in (0, 2, 9, 14, 3):
         out, stats = _gpu_image(rtm, data, "repaired", -1, 21, want=("f64",), variant=v)
         assert np.array_equal(out["f64"], ref), (n, v, "unlimited")
         assert stats["casts"] == cnt["casts"]
@@ -1379,3 +1380,68 @@ def test_renderer_reads_the_live_scene(rtm, oracle):
     assert not _bits_equal(c, d)
     data.object[1], data.object[2] = data.object[2], data.object[1]  # reorder: same objects, nothing written
     both()
+
+
+def test_retired_variants_are_refused_by_name(rtm, oracle):
+    """Variants retired from the product (profiles/r3/retired_variants.patch) keep their numbers, say so in their
+    names, and are refused — never silently served by another kernel."""
+    data = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    data.width, data.height, data.samples, data.superSamples = 16, 16, 1, 1
+    retired = [v for v in range(rtm.lib().rtm_num_variants()) if rtm.lib().rtm_variant_name(v).startswith(b"retired")]
+    assert retired == [4, 5, 6, 8, 10, 11, 13]
+    for v in retired + [rtm.lib().rtm_num_variants(), -1]:
+        with pytest.raises(rtm.RtmError) as e:
+            _gpu_image(rtm, data, "repaired", 8, 1, want=("f64",), variant=v)
+        assert e.value.status == -8
+    assert b"profiles/r3/retired_variants.patch" in rtm.lib().rtm_variant_name(13)
+
+
+def test_scene_destroy_and_stream_release_do_not_wait_for_other_work(rtm, oracle):
+    """include/rtm.h: rtm_scene_destroy never waits — a scene whose renders are still running is parked and freed by a
+    later call — and never for other streams; rtm_stream_release waits for ITS stream only and forgets the pair."""
+    import time
+    import torch
+    L = rtm.lib()
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    big = rtm.LoadData(scene).data
+    big.width, big.height, big.samples, big.superSamples = 1920, 1080, 16, 4   # ~45 ms of GPU time per frame
+    small = rtm.LoadData(scene).data
+    small.width, small.height, small.samples, small.superSamples = 64, 40, 2, 2
+    ost, oarr, on = oracle.load_scene(scene, width=64, height=40, samples=2, super_samples=2)
+    ref, _ = oracle.render(ost, oarr, on, oracle.make_options(mode=1, max_bounces=8, seed=3, height=40))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    rbig = rtm.Renderer(big, mode="repaired", max_bounces=8, seed=3)
+    rsmall = rtm.Renderer(small, mode="repaired", max_bounces=8, seed=3)
+    rbig.render_rows_device(want=("f32",), stats=False, stream=sa.cuda_stream)      # warm both contexts
+    out_small, _ = rsmall.render_rows_device(want=("f64",), stats=False, stream=sb.cuda_stream)
+    torch.cuda.synchronize()
+    # (1) a finished scene on stream B is destroyed while stream A is busy for ~0.5 s: no wait for A
+    for _ in range(12):
+        rbig.render_rows_device(want=("f32",), stats=False, stream=sa.cuda_stream)
+    out_small, _ = rsmall.render_rows_device(want=("f64",), stats=False, stream=sb.cuda_stream)
+    sb.synchronize()
+    t0 = time.perf_counter()
+    rsmall.invalidate()                                       # rtm_scene_destroy
+    t_destroy_idle = time.perf_counter() - t0
+    busy_after = not sa.query()
+    # (2) the scene of the renders that are still running: parked, the call returns at once, the frames stay right
+    frames = [rbig.render_rows_device(want=("f32",), stats=False, stream=sa.cuda_stream)[0]["f32"] for _ in range(2)]
+    t0 = time.perf_counter()
+    rbig.invalidate()
+    t_destroy_busy = time.perf_counter() - t0
+    still_busy = not sa.query()
+    sa.synchronize()
+    print(f"destroy of an idle scene with another stream busy: {t_destroy_idle * 1e3:.2f} ms; of a scene in use: "
+          f"{t_destroy_busy * 1e3:.2f} ms (stream busy after: {busy_after}, {still_busy})")
+    assert busy_after and still_busy, "the box was too fast for this test's timing: nothing was in flight"
+    assert t_destroy_idle < 0.05 and t_destroy_busy < 0.05
+    assert _bits_equal(out_small["f64"].cpu().numpy(), ref)
+    assert torch.equal(frames[0], frames[1])
+    check, _ = rtm.Renderer(big, mode="repaired", max_bounces=8, seed=3).render_rows_device(want=("f32",))
+    assert torch.equal(frames[0], check["f32"])
+    # (3) rtm_stream_release: waits for its own stream, then the pair is unknown again (a second release is a no-op)
+    rsmall.render_rows_device(want=("f64",), stats=False, stream=sb.cuda_stream)
+    assert L.rtm_stream_release(0, C.c_void_p(sb.cuda_stream)) == 0 and sb.query()
+    assert L.rtm_stream_release(0, C.c_void_p(sb.cuda_stream)) == 0
+    out2, _ = rsmall.render_rows_device(want=("f64",), stats=True, stream=sb.cuda_stream)   # a fresh context is made
+    assert _bits_equal(out2["f64"].cpu().numpy(), ref)
