@@ -175,8 +175,9 @@ int rtm_stream_release(int device, void* stream);
 int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
                      rtm_scene** out_scene);
 /* The same for a list of objects of any type (spheres and planes in the reference's vector order, which
- * decides ties: the lowest index wins).  Scenes that contain a plane are rendered by the general per-object
- * kernel (variant 1); rtm_options.variant must be 0 or 1 for them.  HOST pointer. */
+ * decides ties: the lowest index wins).  Scenes that contain a plane are rendered by the default chunked kernel
+ * up to 255 objects (rtm_options.variant 0, 2 or 9) and by the general per-object kernel beyond (variant 1, which
+ * may also be asked for); the other variants know spheres only and refuse them.  HOST pointer. */
 int rtm_scene_create_objects(const rtm_object* objects, size_t n_objects, int device, rtm_scene** out_scene);
 int rtm_scene_destroy(rtm_scene* scene);
 size_t rtm_scene_size(const rtm_scene* scene);

@@ -230,10 +230,13 @@ constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 app
 constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
 constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
 
+//   PLANES  (with LDS_TAB) the scene holds png::PlaneObject entries: SceneLdsObjects / object_chunk / MathSpecZ
+//           (rtm_path.h) — a plane's test in its index slot of the chunk, its normal from the LDS table
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
           bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false,
-          bool REUSE = false>
+          bool REUSE = false, bool PLANES = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
+    static_assert(!PLANES || (LDS_TAB && !REUSE), "plane scenes ride on the LDS tables");
     static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
     static_assert(!REUSE || (DEFER && PACK8 && !SPLIT), "primary-hit reuse rides on the deferred fold with packed records");
     static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
@@ -269,6 +272,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
         for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
         for (int i = lane; i < P.scene.n; i += 64) {
+            if (PLANES && gsrc[i * 4 + 3] < 0.0) {  // a plane's row: its normal (SceneLdsObjects::plane_normal)
+                lnrm[i * 3] = P.scene.plane[(size_t)i * 16 + 3];
+                lnrm[i * 3 + 1] = P.scene.plane[(size_t)i * 16 + 4];
+                lnrm[i * 3 + 2] = P.scene.plane[(size_t)i * 16 + 5];
+                continue;
+            }
             const double ms = (double)__builtin_sqrtf((float)gsrc[i * 4 + 3]);
             lnrm[i * 3] = ms;
             lnrm[i * 3 + 1] = refined_rcp_or_nan(ms);
@@ -276,7 +285,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         }
         __syncthreads();  // one wave per block: orders the LDS writes before the reads
     }
-    using Scene = typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type;
+    using Scene = typename std::conditional<PLANES, SceneLdsObjects,
+                                            typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type>::type;
     Scene sc;
     sc.v = P.scene;
     if constexpr (LDS_TAB) {
@@ -1082,19 +1092,62 @@ __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n
 }
 
 // ---- RAII for everything the host side owns: an early return (RTM_HIP_CHECK) releases it -------
+// A library-owned stream per device for allocations that must come and go WITHOUT a device-wide wait: hipFree (like
+// hipMalloc) synchronises the whole device — measured: destroying an idle scene took the 0.5 s another stream was busy
+// for — while a stream-ordered free on this stream only returns the block to the device's memory pool.  Heap objects
+// that are never destroyed (no HIP calls from static destructors at exit).
+inline hipStream_t pool_stream(int device) {
+    static std::mutex* mu = new std::mutex;
+    static std::map<int, hipStream_t>* streams = new std::map<int, hipStream_t>;
+    std::lock_guard<std::mutex> lock(*mu);
+    auto it = streams->find(device);
+    if (it != streams->end()) return it->second;
+    hipStream_t st = nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device);
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+        uint64_t keep = ~(uint64_t)0;  // freed blocks stay in the pool instead of going back to the driver at every sync
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    if (prev >= 0) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
+    (*streams)[device] = st;
+    return st;
+}
+
 struct DevMem {
     void* p = nullptr;
+    int pooled_device = -1;  // >= 0: from the device's memory pool through pool_stream (alloc_pooled)
     DevMem() = default;
     DevMem(const DevMem&) = delete;
     DevMem& operator=(const DevMem&) = delete;
     ~DevMem() { reset(); }
     void reset() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pooled_device >= 0) (void)hipFreeAsync(p, pool_stream(pooled_device));
+            else (void)hipFree(p);
+        }
         p = nullptr;
+        pooled_device = -1;
     }
     int alloc(size_t bytes) {
         reset();
         RTM_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+        return RTM_OK;
+    }
+    // Stream-ordered allocation on the library's own stream, waited for here (nothing else is ever queued on that
+    // stream, so the wait is for the allocation alone): the block is usable on every stream on return, and its
+    // release (reset) does not wait for the device.
+    int alloc_pooled(size_t bytes, int device) {
+        reset();
+        hipStream_t st = pool_stream(device);
+        if (!st) return alloc(bytes);
+        RTM_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 1, st));
+        pooled_device = device;
+        RTM_HIP_CHECK(hipStreamSynchronize(st));
         return RTM_OK;
     }
     template <typename T>
@@ -1205,9 +1258,9 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     sc.n = n;
     std::vector<double> hg, hm;
     flatten_scene(sp, n, hg, hm);
-    int rc = sc.geom.alloc((n ? n : 1) * 4 * sizeof(double));
-    if (rc == RTM_OK) rc = sc.mat.alloc((n + 1) * 8 * sizeof(double));
-    if (rc == RTM_OK) rc = sc.aux.alloc(scene_aux_doubles(n) * sizeof(double));
+    int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
     if (rc != RTM_OK) return rc;
     if (n) RTM_HIP_CHECK(hipMemcpy(sc.geom.p, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice));
     RTM_HIP_CHECK(hipMemcpy(sc.mat.p, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1221,9 +1274,9 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
     RTM_HIP_CHECK(hipSetDevice(device));
     sc.device = device;
     sc.n = n;
-    int rc = sc.geom.alloc((n ? n : 1) * 4 * sizeof(double));
-    if (rc == RTM_OK) rc = sc.mat.alloc((n + 1) * 8 * sizeof(double));
-    if (rc == RTM_OK) rc = sc.aux.alloc(scene_aux_doubles(n) * sizeof(double));
+    int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
     if (rc != RTM_OK) return rc;
     flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256>>>(sp_dev, n, sc.geom.as<double>(), sc.mat.as<double>());
     RTM_HIP_CHECK(hipGetLastError());
@@ -1296,7 +1349,7 @@ int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene
         for (size_t i = 0; i < n; ++i)
             if (objs[i].type == RTM_OBJECT_PLANE) hg[i * 4 + 3] = -1.0;
         RTM_HIP_CHECK(hipMemcpy(sc->geom.p, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice));
-        if ((rc = sc->plane.alloc(rows.size() * sizeof(double))) != RTM_OK) return rc;
+        if ((rc = sc->plane.alloc_pooled(rows.size() * sizeof(double), device)) != RTM_OK) return rc;
         RTM_HIP_CHECK(hipMemcpy(sc->plane.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
         sc->has_planes = true;
     }
@@ -1648,6 +1701,19 @@ static size_t debug_lds_pad() {
     return pad;
 }
 
+// Scenes that hold planes (render_view: up to kLdsTableMaxSpheres objects): the deferred-fold kernels with the object
+// chunk, packed records for a depth cap of at most 8 (PACK8), by position for any depth (PACKL)
+template <bool SPLIT>
+static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream_t stream) {
+    const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
+    if (P.max_bounces >= 0 && P.max_bounces <= 8)
+        render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
+            <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
+    else
+        render_tiles_kernel<MathFast, true, 8, uint8_t, 0, 4, true, false, false, SPLIT, true, true, false, true>
+            <<<grid, 64, tab + kFoldQueueBytesL, stream>>>(P);
+}
+
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
           bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
@@ -1703,6 +1769,15 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
             else launch_render_depth<MathRef, false, 1, uint32_t>(P, grid, stream);
             return;
         case kVariantFastLds:  // (n < 8: no full chunk of 8, the instantiation without the chunk loop)
+            if (P.scene.plane != nullptr) {  // render_view: n <= kLdsTableMaxSpheres (ids and the identity index in a byte: n < 256)
+                if (P.split > 1) {
+                    launch_render_planes<true>(P, split_grid, stream);
+                    split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+                } else {
+                    launch_render_planes<false>(P, grid, stream);
+                }
+                return;
+            }
             if (P.split > 1) {
                 if (n < 8) launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
                 else launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
@@ -2199,12 +2274,18 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                   n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
     else if (variant == kVariantSplit)
         variant = kVariantFastLds;
-    if (view.plane != nullptr) {  // png::PlaneObject in the scene: the per-object loop with the compiler's math
-        if (opt->variant != kVariantAuto && opt->variant != kVariantRef) {
-            set_last_error("scenes that hold planes are rendered by variant 0 (auto) or 1 (per-object loop)");
+    if (view.plane != nullptr) {
+        // png::PlaneObject in the scene: the chunked LDS-table kernels serve it up to 255 objects (variants 0, 2, 9), the
+        // per-object loop with the compiler's math (variant 1) any size; the other kernels know spheres only
+        if (opt->variant != kVariantAuto && opt->variant != kVariantRef && opt->variant != kVariantFastLds &&
+            opt->variant != kVariantSplit) {
+            set_last_error("scenes that hold planes are rendered by variants 0 (auto), 1 (per-object loop), 2 and 9");
             return RTM_ERR_UNSUPPORTED;
         }
-        variant = kVariantRef;
+        if (opt->variant == kVariantRef || n >= 256)
+            variant = kVariantRef;
+        else
+            variant = kVariantFastLds;
     }
     // beyond what their records / tables hold, the packed-record and the stamped kernels hand over to the global-table one
     if ((variant == kVariantStamped && n > (size_t)kLdsTableMaxSpheres) || (variant == kVariantGlobalDefer && n >= 256))

@@ -34,6 +34,7 @@ namespace rtm {
 struct MathRef {
     static __device__ __forceinline__ double sqrt64(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ D3 div3(D3 a, double y) { return a / y; }
+    static __device__ __forceinline__ double div(double x, double y) { return x / y; }
     template <int K>
     static __device__ __forceinline__ void sqrt64_batch(const double (&x)[K], double (&out)[K]) {
 #pragma unroll
@@ -161,6 +162,19 @@ struct MathFast {
 #pragma unroll
         for (int k = 0; k < K; ++k) out[k] = __builtin_fma(d1[k], h1[k], s2[k]);
     }
+    // one division (the plane test's t): the same sequence for a single numerator
+    static __device__ __forceinline__ double div(double x, double y) {
+        const bool ok = moderate(y) && moderate(x);
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0) return x / y;
+        double r = __builtin_amdgcn_rcp(y);
+        double e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        const double q = x * r;
+        const double rem = __builtin_fma(-y, q, x);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
+    }
     static __device__ __forceinline__ D3 div3(D3 a, double y) {
         const bool ok = moderate(y) && moderate(a.x) && moderate(a.y) && moderate(a.z);
         if (__builtin_amdgcn_ballot_w64(!ok) != 0) return a / y;
@@ -183,7 +197,15 @@ struct MathFast {
 // compiler's own (bit-identical) expansion.  The caller checks `bad` once per block with a ballot
 // and re-runs the block with MathRef if any lane tripped it — one branch per block instead of one
 // per operation, and one long basic block for the scheduler.
-struct MathSpec {
+// GUARD (the default flavour, MathSpec): the guards of a Normalize reduced to ONE compare of the smallest squared
+// component, no v_div_fixup behind them — which costs the ability to pass an exactly zero component through (it trips
+// `bad`).  Fine for sphere normals and random bounce directions, where a zero component is a measure-zero event;
+// useless for PLANE normals, which are axis-aligned more often than not.  MathSpecZ = MathSpecT<false> keeps the
+// v_div_fixup and the per-operand exponent checks (zeros, infinities and NaNs are settled by the fix-up exactly as in
+// the compiler's sequence) and serves the scenes that hold planes.
+template <bool GUARD>
+struct MathSpecT {
+    static constexpr bool kGuard = GUARD;
     bool bad = false;
     const double* trig_lds = nullptr;  // LDS copy of the sincos constants (optional)
     __device__ __forceinline__ double sqrt64(double x) {
@@ -236,7 +258,6 @@ struct MathSpec {
         bad = bad || !sqrtf_fast_ok(len2);
         return (double)sqrtf_fast(len2);
     }
-#if RTM_OPT_GUARD
     // The three divisions x / m, m = (double)sqrtf((float)(x.x)) of a Normalize, with the guard reduced to what
     // can actually go wrong.  sqrtf_fast_ok(len2) already pins m to [2^-48, 2^64) — always "moderate" — and
     // every |x_i| to < 2^64, and a NaN or infinite component makes len2 NaN or infinite, which it rejects.
@@ -267,28 +288,30 @@ struct MathSpec {
         return D3{one(a.x), one(a.y), one(a.z)};
     }
     __device__ __forceinline__ D3 normalize(D3 a) {
-        const double sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
-        return div3_by_magnitude(a, sx, sy, sz, (float)(sx + sy + sz));
+        if constexpr (GUARD) {
+            const double sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
+            return div3_by_magnitude(a, sx, sy, sz, (float)(sx + sy + sz));
+        } else {
+            return div3(a, magnitude_spec(a));
+        }
     }
-#else
-    __device__ __forceinline__ D3 normalize(D3 a) { return div3(a, magnitude_spec(a)); }
-#endif
     // Normalize of a vector whose y component is a (signed) zero — Cross((0,1,0), w) for finite w:
     // y*y adds +0 to the squared length and +-0 / m is the same +-0, so only x and z are divided.
     // Anything else in y (NaN from a non-finite w) trips `bad`.
     __device__ __forceinline__ D3 normalize_y0(D3 a) {
-#if RTM_OPT_GUARD
-        const double sx = a.x * a.x, sz = a.z * a.z;
-        const float len2 = (float)(sx + sz);
-        const unsigned hx = (unsigned)__double2hiint(sx), hz = (unsigned)__double2hiint(sz);
-        bad = bad | !sqrtf_fast_ok(len2) | !(a.y == 0.0) | ((hx < hz ? hx : hz) < 0x0DF00000u);  // see div3_by_magnitude
-        const double y = (double)sqrtf_fast(len2);
-#else
-        const float len2 = (float)(a.x * a.x + a.z * a.z);
-        bad = bad || !sqrtf_fast_ok(len2) || !(a.y == 0.0);
-        const double y = (double)sqrtf_fast(len2);
-        bad = bad || !(MathFast::moderate(a.x) && MathFast::moderate(a.z));  // y: a normal float here
-#endif
+        double y;
+        if constexpr (GUARD) {
+            const double sx = a.x * a.x, sz = a.z * a.z;
+            const float len2 = (float)(sx + sz);
+            const unsigned hx = (unsigned)__double2hiint(sx), hz = (unsigned)__double2hiint(sz);
+            bad = bad | !sqrtf_fast_ok(len2) | !(a.y == 0.0) | ((hx < hz ? hx : hz) < 0x0DF00000u);  // see div3_by_magnitude
+            y = (double)sqrtf_fast(len2);
+        } else {
+            const float len2 = (float)(a.x * a.x + a.z * a.z);
+            bad = bad || !sqrtf_fast_ok(len2) || !(a.y == 0.0);
+            y = (double)sqrtf_fast(len2);
+            bad = bad || !(MathFast::moderate(a.x) && MathFast::moderate(a.z));  // y: a normal float here
+        }
         double r = __builtin_amdgcn_rcp(y);
         double e = __builtin_fma(-y, r, 1.0);
         r = __builtin_fma(r, e, r);
@@ -301,9 +324,8 @@ struct MathSpec {
         };
         return D3{one(a.x), a.y, one(a.z)};
     }
-#if RTM_OPT_ONB
     // Normalize of (cx, +-0, cz): the two non-zero components of normalize_y0, for the caller that has
-    // established the zero structurally and does not need it back.
+    // established the zero structurally and does not need it back (GUARD flavour only).
     __device__ __forceinline__ void normalize_xz(double cx, double cz, double& ux, double& uz) {
         const double sx = cx * cx, sz = cz * cz;
         const float len2 = (float)(sx + sz);
@@ -323,46 +345,65 @@ struct MathSpec {
         ux = one(cx);
         uz = one(cz);
     }
-#endif
     // Normalize(hit - centre) (src/SettingData.cpp:214-215) for a hit point that is ON its sphere to
     // float precision: then (float)|dv|^2 is exactly (float)(r*r), so Magnitude returns the
     // per-sphere constant `ms` and the reciprocal refinement of the three divisions is the
     // per-sphere constant `rinv` (both precomputed with the same instruction sequence).  Taken only
     // when every active lane is in that case; otherwise the general Normalize runs.
     __device__ __forceinline__ D3 normalize_on_sphere(D3 dv, double ms, double rinv, float r2f) {
-#if RTM_OPT_GUARD
-        const double sx = dv.x * dv.x, sy = dv.y * dv.y, sz = dv.z * dv.z;
-        const float len2f = (float)(sx + sy + sz);
-        const bool canon = (len2f == r2f) && (rinv == rinv);
-        if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3_by_magnitude(dv, sx, sy, sz, len2f);
-        // canonical: |dv|^2 rounds to the float r*r of a sphere whose refined reciprocal exists (rinv is NaN when
-        // ms is outside the exact range), so only a tiny component remains to be excluded
-        unsigned lo = (unsigned)__double2hiint(sx);
-        const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
-        lo = hy < lo ? hy : lo;
-        lo = hz < lo ? hz : lo;
-        bad = bad | (lo < 0x0DF00000u);
-#else
-        const float len2f = (float)(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
-        const bool canon = (len2f == r2f) && (rinv == rinv);
-        if (__builtin_amdgcn_ballot_w64(!canon) != 0) {
-            bad = bad || !sqrtf_fast_ok(len2f);
-            return div3(dv, (double)sqrtf_fast(len2f));
+        if constexpr (GUARD) {
+            const double sx = dv.x * dv.x, sy = dv.y * dv.y, sz = dv.z * dv.z;
+            const float len2f = (float)(sx + sy + sz);
+            const bool canon = (len2f == r2f) && (rinv == rinv);
+            if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3_by_magnitude(dv, sx, sy, sz, len2f);
+            // canonical: |dv|^2 rounds to the float r*r of a sphere whose refined reciprocal exists (rinv is NaN when
+            // ms is outside the exact range), so only a tiny component remains to be excluded
+            unsigned lo = (unsigned)__double2hiint(sx);
+            const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
+            lo = hy < lo ? hy : lo;
+            lo = hz < lo ? hz : lo;
+            bad = bad | (lo < 0x0DF00000u);
+            auto one = [&](double x) {
+                const double q = x * rinv;
+                const double rem = __builtin_fma(-ms, q, x);
+                return __builtin_fma(rem, rinv, q);  // no v_div_fixup: see div3_by_magnitude
+            };
+            return D3{one(dv.x), one(dv.y), one(dv.z)};
+        } else {
+            const float len2f = (float)(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
+            const bool canon = (len2f == r2f) && (rinv == rinv);
+            if (__builtin_amdgcn_ballot_w64(!canon) != 0) {
+                bad = bad || !sqrtf_fast_ok(len2f);
+                return div3(dv, (double)sqrtf_fast(len2f));
+            }
+            bad = bad || !(MathFast::moderate(dv.x) && MathFast::moderate(dv.y) && MathFast::moderate(dv.z));
+            auto one = [&](double x) {
+                const double q = x * rinv;
+                const double rem = __builtin_fma(-ms, q, x);
+                return __builtin_amdgcn_div_fixup(__builtin_fma(rem, rinv, q), ms, x);
+            };
+            return D3{one(dv.x), one(dv.y), one(dv.z)};
         }
-        bad = bad || !(MathFast::moderate(dv.x) && MathFast::moderate(dv.y) && MathFast::moderate(dv.z));
-#endif
-        auto one = [&](double x) {
-            const double q = x * rinv;
-            const double rem = __builtin_fma(-ms, q, x);
-#if RTM_OPT_GUARD
-            return __builtin_fma(rem, rinv, q);  // no v_div_fixup: see div3_by_magnitude
-#else
-            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, rinv, q), ms, x);
-#endif
-        };
-        return D3{one(dv.x), one(dv.y), one(dv.z)};
+    }
+    // One correctly rounded division x / y (the plane test's t = n.(p - o) / n.d): the unscaled sequence with the fix-up
+    __device__ __forceinline__ double div(double x, double y) {
+        bad = bad || !(MathFast::moderate(y) && MathFast::moderate(x));
+        double r = __builtin_amdgcn_rcp(y);
+        double e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-y, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        const double q = x * r;
+        const double rem = __builtin_fma(-y, q, x);
+        return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), y, x);
     }
 };
+using MathSpec = MathSpecT<RTM_OPT_GUARD != 0>;
+using MathSpecZ = MathSpecT<false>;
+template <class T>
+struct is_spec : std::false_type {};
+template <bool G>
+struct is_spec<MathSpecT<G>> : std::true_type {};
 // the reciprocal refinement MathFast/MathSpec::div3 apply to a denominator (v_rcp_f64 + two
 // Newton steps), or NaN when the denominator is outside their exact range
 __device__ __forceinline__ double refined_rcp_or_nan(double y) {
@@ -493,6 +534,7 @@ __device__ __forceinline__ double4 load_geom_uniform(const double4* geom, int i)
 struct SceneGlobal {
     SceneView v;
     static constexpr bool kHasNormTable = false;
+    static constexpr bool kPlanes = false;  // (planes, if any, are found at run time: v.plane, the per-object loop)
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -520,6 +562,7 @@ struct SceneLds {
     const double* lnrm;   // LDS, 3 doubles per sphere: |hit - centre| as Magnitude returns it for a point
                           // on the sphere, (double)sqrtf((float)(r*r)), its refined reciprocal, the float r*r
     static constexpr bool kHasNormTable = true;
+    static constexpr bool kPlanes = false;
     __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 3]; }
     __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 3 + 1]; }
     __device__ __forceinline__ float norm_r2f(int id) const { return reinterpret_cast<const float*>(lnrm + id * 3 + 2)[0]; }
@@ -528,6 +571,40 @@ struct SceneLds {
     __device__ __forceinline__ D3 center(int id) const {
         const double* g = lgeom + id * 4;
         return D3{g[0], g[1], g[2]};
+    }
+    __device__ __forceinline__ double kd(int id) const { return lmat[id * 8 + 6]; }
+    __device__ __forceinline__ double kd24(int id) const { return lmat[id * 8 + 7]; }
+    __device__ __forceinline__ D3 emission(int id) const {
+        const double* m = lmat + id * 8;
+        return D3{m[3], m[4], m[5]};
+    }
+    __device__ __forceinline__ D3 color_kd(int id) const {
+        const double* m = lmat + id * 8;
+        return D3{m[0], m[1], m[2]};
+    }
+};
+
+// Small scenes that hold png::PlaneObject entries (include/rtm.h: rtm_object), for the chunked fast kernels: the same
+// LDS tables, where a plane's geometry row is (position, negative "r*r") and its 3-double row of the normal-length
+// table holds the plane's NORMAL instead (a sphere's normal-length shortcut is not used in such scenes).  A plane's
+// 14 test operands are wave-uniform like a sphere's geometry and come by scalar loads from v.plane.
+struct SceneLdsObjects {
+    SceneView v;
+    const double* lgeom;  // LDS, 4 doubles per object
+    const double* lmat;   // LDS, 8 doubles per object
+    const double* lnrm;   // LDS, 3 doubles per object: a plane's m_normal (unused for spheres)
+    static constexpr bool kHasNormTable = false;
+    static constexpr bool kPlanes = true;
+    __device__ __forceinline__ int n() const { return v.n; }
+    __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
+    __device__ __forceinline__ D3 center(int id) const {
+        const double* g = lgeom + id * 4;
+        return D3{g[0], g[1], g[2]};
+    }
+    __device__ __forceinline__ bool is_plane(int id) const { return __double2hiint(lgeom[id * 4 + 3]) < 0; }
+    __device__ __forceinline__ D3 plane_normal(int id) const {
+        const double* q = lnrm + id * 3;
+        return D3{q[0], q[1], q[2]};
     }
     __device__ __forceinline__ double kd(int id) const { return lmat[id * 8 + 6]; }
     __device__ __forceinline__ double kd24(int id) const { return lmat[id * 8 + 7]; }
@@ -685,6 +762,66 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
     sphere_chunk_g<M, K, EARLY_OUT>(g, i0, org, dir, dis, hit_object);
 }
 
+// png::PlaneObject::Intersect as this build completes it (plane_test above) fused with the caller's acceptance test
+// (src/Renderer.cpp:67), select-only.  plane_test returns false on  |n.d| < FLT_EPSILON,  !(t > 0.001),  |d.right| >
+// right.right  and  |d.upv| > upv.upv  in that order; none of the tests has a side effect, so
+//   hit == !(|n.d| < eps) && (t > 0.001) && !(|d.right| > rr) && !(|d.upv| > uu)
+// with every comparison false for a NaN operand exactly as in the statement form, and the caller's "t < dis && t > 0"
+// adds "t < dis" (t > 0.001 already holds).  `pl` is wave-uniform: its 14 doubles arrive by scalar loads.
+template <class M>
+__device__ __forceinline__ void plane_update(const double* pl_global, const D3 org, const D3 dir, const int index,
+                                             double& dis, int& hit_object) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+    ConstF64Ptr pl = (ConstF64Ptr)(unsigned long long)pl_global;
+#else
+    const double* pl = pl_global;
+#endif
+    const D3 pos = d3(pl[0], pl[1], pl[2]), nrm = d3(pl[3], pl[4], pl[5]);
+    const double dn = dot(nrm, dir);
+    const double tt = M::div(dot(nrm, pos - org), dn);
+    const D3 d = (org + dir * tt) - pos;
+    const D3 right = d3(pl[6], pl[7], pl[8]), upv = d3(pl[9], pl[10], pl[11]);
+    const double dr = dot(d, right), du = dot(d, upv);
+    const bool hit = !(fabs(dn) < (double)FLT_EPSILON) && (tt > 0.001) && !(fabs(dr) > pl[12]) && !(fabs(du) > pl[13]);
+    const bool accept = hit && (tt < dis);
+    dis = accept ? tt : dis;
+    hit_object = accept ? index : hit_object;
+}
+
+// K consecutive OBJECTS of a scene that holds planes.  The type of object i is wave-uniform (the sign of its geometry
+// row's fourth entry), so every per-object decision below is a scalar branch: spheres keep the batch structure of
+// sphere_chunk (independent discriminant chains, ONE guard for the K square roots — a plane's slot carries NaN, which
+// the unscaled sequence passes through and no compare accepts), and the acceptance updates run in index order with a
+// plane's own test in its slot, so strict < still lets the lowest index win ties across both types.
+template <class M, int K, class Scene>
+__device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir, double& dis,
+                                             int& hit_object) {
+    double b[K], D4[K], sq[K];
+    bool plane[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double4 g = sc.geom_uniform(i0 + k);
+        plane[k] = __double2hiint(g.w) < 0;  // wave-uniform
+        if (plane[k]) {
+            b[k] = 0.0;
+            D4[k] = __builtin_nan("");
+        } else {
+            const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
+            b[k] = dot(p_o, dir);                                      // :199
+            D4[k] = b[k] * b[k] - dot(p_o, p_o) + g.w;                 // :200
+        }
+    }
+    M::template sqrt64_batch_hit<K>(D4, sq);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (plane[k])
+            plane_update<M>(sc.v.plane + (size_t)(i0 + k) * 16, org, dir, i0 + k, dis, hit_object);
+        else
+            accept_update(b[k], sq[k], i0 + k, dis, hit_object);
+    }
+}
+
 // src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
 // UNROLL == 1: the literal loop.  UNROLL > 1: batches of UNROLL spheres (sphere_batch).
 template <class M, int UNROLL, class Scene>
@@ -709,6 +846,17 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
     } else {
         // UNROLL < 0: the caller guarantees n < -UNROLL, so there is no full chunk and the loop is not even
         // compiled (it is what sets the kernel's register high-water mark)
+        if constexpr (Scene::kPlanes) {  // scenes with planes: chunks of 4 objects plus an exact tail
+            int i0 = 0;
+            for (; i0 + 4 <= n; i0 += 4) object_chunk<M, 4>(sc, i0, org, dir, dis, hit_object);
+            switch (n - i0) {  // wave-uniform
+                case 1: object_chunk<M, 1>(sc, i0, org, dir, dis, hit_object); break;
+                case 2: object_chunk<M, 2>(sc, i0, org, dir, dis, hit_object); break;
+                case 3: object_chunk<M, 3>(sc, i0, org, dir, dis, hit_object); break;
+                default: break;
+            }
+            return hit_object;
+        }
         if constexpr (UNROLL <= -101 && UNROLL >= -107) {
             // the caller guarantees n == -UNROLL - 100: the scene is ONE exact chunk, no switch, no other sizes
             // compiled in (scenes under 8 spheres; the launcher picks the instantiation)
@@ -789,15 +937,24 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     // D2: in literal mode the caller's normal stays (0,0,0); repaired: src/SettingData.cpp:214-215
     D3 normal = d3(0, 0, 0);
     if (mode != RTM_MODE_LITERAL) {
-        if (sc.v.plane != nullptr) {  // wave-uniform: the scene holds planes (per-object kernel, MathRefI)
+        if constexpr (Scene::kPlanes) {  // the fast kernels' instantiation for scenes that hold planes (MathSpecZ)
+            const bool is_plane = sc.is_plane(id);
+            // a plane lane's "hit - position" is no sphere radius: whatever its Normalize trips must not count
+            [[maybe_unused]] bool bad_before = false;
+            if constexpr (is_spec<MI>::value) bad_before = m.bad;
+            const D3 nsphere = normalize_i(m, hit_point - sc.center(id));
+            if constexpr (is_spec<MI>::value) m.bad = bad_before || (m.bad && !is_plane);
+            const D3 pn = sc.plane_normal(id);
+            normal = is_plane ? pn : nsphere;  // PlaneObject: out_normal = m_normal
+        } else if (sc.v.plane != nullptr) {  // wave-uniform: the scene holds planes (per-object kernel, MathRefI)
             const bool is_plane = sc.v.geom[id].w < 0.0;
             const double* pl = sc.v.plane + (size_t)id * 16;
             const D3 nsphere = normalize_i(m, hit_point - sc.center(id));
             normal = is_plane ? d3(pl[3], pl[4], pl[5]) : nsphere;  // PlaneObject: out_normal = m_normal
-            if constexpr (std::is_same<MI, MathSpec>::value) m.bad = m.bad | is_plane;  // its shortcuts assume spheres
+            if constexpr (is_spec<MI>::value) m.bad = m.bad | is_plane;  // its shortcuts assume spheres
         } else {
             const D3 dv = hit_point - sc.center(id);
-            if constexpr (Scene::kHasNormTable && std::is_same<MI, MathSpec>::value)
+            if constexpr (Scene::kHasNormTable && is_spec<MI>::value)
                 normal = m.normalize_on_sphere(dv, sc.norm_m(id), sc.norm_rinv(id), sc.norm_r2f(id));
             else
                 normal = normalize_i(m, dv);
@@ -820,7 +977,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     const bool some_x_axis = __builtin_amdgcn_ballot_w64(!use_y) != 0;  // some lane has |w.x| <= FLT_MIN (e.g. literal mode)
     double sn, cs;
 #if RTM_OPT_ONB
-    if constexpr (std::is_same<MI, MathSpec>::value) {
+    if constexpr (std::is_same<MI, MathSpecT<true>>::value) {  // the guarded flavour only: it has excluded zero components
         if (!some_x_axis) {
             // The orthonormal basis with the structural zeros of Cross((0,1,0), w) taken out — exact, not
             // approximate, GIVEN that no component of w is zero, which is what the guard of the normal's
@@ -913,7 +1070,7 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
                                                 RngStream& rng, D3& term, PathCounters& pc, PushFn push,
                                                 const double* trig_lds = nullptr) {
     ShadeOut o;
-    MathSpec m;
+    typename std::conditional<Scene::kPlanes, MathSpecZ, MathSpec>::type m;  // plane normals have exact zeros: see MathSpecT
     m.trig_lds = trig_lds;
     bool cont = path_shade_core(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {

@@ -614,7 +614,7 @@ def test_edge_case_scenes_vs_oracle(rtm, oracle, name):
     for mode, mb in (("repaired", 8), ("repaired", 3), ("repaired", 1), ("repaired", 0), ("literal", -1), ("literal", 2)):
         m = oracle.MODE_REPAIRED if mode == "repaired" else oracle.MODE_LITERAL
         ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=17, height=27))
-        for v in (0, 1, 4, 8, 9, 13):
+        for v in (0, 1, 3, 12, 9, 14):
             out, stats = _gpu_image(rtm, data, mode, mb, 17, want=("f64",), variant=v)
             assert np.allclose(out["f64"], ref, rtol=0, atol=PIXEL_TOL, equal_nan=True), (name, mode, mb, v)
             assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"]), (name, mode, mb, v)
@@ -1200,27 +1200,78 @@ def test_plane_intersect_batch_bit_exact(rtm, oracle, mode):
     assert 0.2 * n < hits < 0.8 * n
 
 
-@pytest.mark.parametrize("max_bounces", [8, -1])
+@pytest.mark.parametrize("max_bounces", [8, -1, 12, 0])
 def test_plane_room_render_vs_oracle(rtm, oracle, max_bounces):
-    """scenes/planeRoom.json — six PlaneObject walls, a square lamp, two spheres — loaded by LoadData (objectType 2)
-    and rendered by the per-object kernel: the oracle's image and counters, bit for bit; the fast kernels refuse it."""
+    """scenes/planeRoom.json — six PlaneObject walls, a square lamp, two spheres — loaded by LoadData (objectType 2):
+    the DEFAULT kernel (the chunked LDS-table kernel with the plane test in the object chunk, packed records for a
+    cap of up to 8 bounces and by position beyond), its sample-split form and the per-object loop with the compiler's
+    math all give the oracle's image and counters, bit for bit; kernels that know spheres only refuse the scene."""
     path = oracle.scene_path("planeRoom.json")
     data = rtm.LoadData(path).data
     assert sum(isinstance(o, rtm.PlaneObject) for o in data.object) == 6 and len(data.object) == 8
     data.width, data.height, data.samples, data.superSamples = 96, 60, 4, 2
-    out, st = _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64", "u8"))
     oobj, n = _oracle_objects(oracle, data)
     ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
     ref, cnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=1, max_bounces=max_bounces, seed=9, height=60))
-    assert _bits_equal(out["f64"], ref) and np.array_equal(out["u8"], oracle.quantise(ref))
-    assert {k: st[k] for k in ("samples", "casts", "bounces", "draws")} == {k: cnt[k] for k in ("samples", "casts", "bounces", "draws")}
-    assert st["variant"] == 1 and ref.max() > 0.5 and st["bounces"] > st["samples"]  # lit, and paths do bounce
-    lit, lst = _gpu_image(rtm, data, "literal", max_bounces, 9, want=("f64",))
     lref, lcnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=0, max_bounces=max_bounces, seed=9, height=60))
-    assert _bits_equal(lit["f64"], lref) and lst["casts"] == lcnt["casts"]
-    with pytest.raises(rtm.RtmError) as e:
-        _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64",), variant=2)
-    assert e.value.status == -8
+    keys = ("samples", "casts", "bounces", "draws")
+    for variant, resolved in ((0, 2), (2, 2), (9, 2), (1, 1)):
+        out, st = _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64", "u8"), variant=variant)
+        assert _bits_equal(out["f64"], ref) and np.array_equal(out["u8"], oracle.quantise(ref)), variant
+        assert {k: st[k] for k in keys} == {k: cnt[k] for k in keys}, variant
+        assert st["variant"] == resolved
+        lit, lst = _gpu_image(rtm, data, "literal", max_bounces, 9, want=("f64",), variant=variant)
+        assert _bits_equal(lit["f64"], lref) and lst["casts"] == lcnt["casts"], variant
+    assert ref.max() > 0.5 and (max_bounces == 0 or cnt["bounces"] > cnt["samples"])  # lit, and paths do bounce
+    for variant in (3, 12, 14, 15, 16):
+        with pytest.raises(rtm.RtmError) as e:
+            _gpu_image(rtm, data, "repaired", max_bounces, 9, want=("f64",), variant=variant)
+        assert e.value.status == -8
+
+
+def test_planes_and_spheres_mixed_scenes_vs_oracle(rtm, oracle):
+    """Planes anywhere in the object list — first, last, between spheres, tilted (no zero component in the normal) and
+    axis-aligned (exact zeros: the shading block's zero-tolerant math), coincident with a sphere's hit distance (the
+    lowest index wins across types), 1 to 40 objects (chunks of four plus every tail size) — default kernel and
+    per-object loop against the oracle, image and counters."""
+    rng = np.random.default_rng(5)
+    cam = rtm.Camera(rtm.vec3(0, 0, -12), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.2)
+    M = rtm.Material
+    for n_obj in (1, 2, 3, 4, 5, 6, 7, 9, 13, 24, 25, 40):
+        objs = []
+        for k in range(n_obj):
+            col = rtm.vec3(*map(float, rng.uniform(0.2, 0.9, 3)))
+            em = rtm.vec3(3.0, 3.0, 3.0) if k % 5 == 0 else rtm.vec3(0, 0, 0)
+            kind = rng.integers(4) if n_obj > 1 else 1
+            pos = rtm.vec3(*map(float, rng.uniform(-5, 5, 3)))
+            if kind == 0:
+                objs.append(rtm.SphereObject(pos, float(rng.uniform(0.5, 2.5)), M(col, em)))
+            elif kind == 1:  # axis-aligned plane facing the origin side
+                axis = int(rng.integers(3))
+                tgt = [pos.x, pos.y, pos.z]
+                tgt[axis] += 1.0 if tgt[axis] < 0 else -1.0
+                up = rtm.vec3(0, 0, 1) if axis == 1 else rtm.vec3(0, 1, 0)
+                objs.append(rtm.PlaneObject(pos, up, rtm.vec3(*tgt), float(rng.uniform(2, 9)), M(col, em)))
+            elif kind == 2:  # tilted plane
+                objs.append(rtm.PlaneObject(pos, rtm.vec3(0.1, 1, 0.2), rtm.vec3(*map(float, rng.uniform(-1, 1, 3))),
+                                            float(rng.uniform(2, 9)), M(col, em)))
+            else:  # a sphere and, right behind it in the list, a plane through its front pole: an exact tie on the axis
+                objs.append(rtm.SphereObject(rtm.vec3(0, 0, 2), 2.0, M(col, em)))
+                objs.append(rtm.PlaneObject(rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), rtm.vec3(0, 0, -1), 3.0, M(col, em)))
+        objs = objs[:max(n_obj, 1)]
+        objs.append(rtm.SphereObject(rtm.vec3(0, 0, 0), 30.0, M(rtm.vec3(0.7, 0.7, 0.7), rtm.vec3(0.4, 0.4, 0.4))))  # the room
+        data = rtm.SettingData(width=48, height=32, samples=3, superSamples=2, camera=cam, object=objs)
+        if not data.has_planes():
+            continue
+        oobj, n = _oracle_objects(oracle, data)
+        ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
+        for mb in (8, -1):
+            ref, cnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=1, max_bounces=mb, seed=31, height=32))
+            for variant in (0, 1):
+                out, st = _gpu_image(rtm, data, "repaired", mb, 31, want=("f64",), variant=variant)
+                assert _bits_equal(out["f64"], ref), (n_obj, mb, variant)
+                assert (st["casts"], st["bounces"], st["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"]), (n_obj, mb, variant)
+                assert st["variant"] == (2 if variant == 0 else 1)
 
 
 def test_fp32_row_statistics(rtm, oracle):
@@ -1389,10 +1440,14 @@ def test_retired_variants_are_refused_by_name(rtm, oracle):
     data.width, data.height, data.samples, data.superSamples = 16, 16, 1, 1
     retired = [v for v in range(rtm.lib().rtm_num_variants()) if rtm.lib().rtm_variant_name(v).startswith(b"retired")]
     assert retired == [4, 5, 6, 8, 10, 11, 13]
-    for v in retired + [rtm.lib().rtm_num_variants(), -1]:
+    for v in retired:
         with pytest.raises(rtm.RtmError) as e:
             _gpu_image(rtm, data, "repaired", 8, 1, want=("f64",), variant=v)
-        assert e.value.status == -8
+        assert e.value.status == -8 and "retired" in str(e.value)
+    for v in (rtm.lib().rtm_num_variants(), -1):  # no such number: an invalid argument, not an unsupported request
+        with pytest.raises(rtm.RtmError) as e:
+            _gpu_image(rtm, data, "repaired", 8, 1, want=("f64",), variant=v)
+        assert e.value.status == -1
     assert b"profiles/r3/retired_variants.patch" in rtm.lib().rtm_variant_name(13)
 
 
