@@ -89,8 +89,66 @@ def cpu_baseline(cfg, budget_rows):
     }
 
 
-def other_configs(rtm, cfg, device, host_trig):
-    """BASELINE configs[1] and a strip of configs[4], measured in this run, outside the timed region."""
+def measured_fp64_peak(rtm):
+    """"FP64 vector 78.6 TF (AMD datasheet; verify by microbenchmark)".  A chip-filling v_fma_f64
+    kernel (rtm_debug_fp64_peak: 8 independent accumulators per lane, 4 and 8 waves per SIMD, >= 60 ms per launch so
+    that the clock has settled), HIP-event time, FMA = 2 flops.  The larger of the two is the measured peak."""
+    import ctypes as C
+    rows = {}
+    for waves in (4, 8):
+        tf, ms = C.c_double(), C.c_double()
+        rtm._lib.check(rtm.lib().rtm_debug_fp64_peak(waves, 60.0, C.byref(tf), C.byref(ms)), "rtm_debug_fp64_peak")
+        rows[f"{waves}_waves_per_simd"] = {"tflops": tf.value, "kernel_ms": ms.value}
+    best = max(v["tflops"] for v in rows.values())
+    return {"value": best, "unit": "TFLOP/s", "measured_in_run": True, "rows": rows,
+            "implied_clock_ghz_at_4_cycles_per_wave_instruction": best * 1e12 / (2 * 64 * 1024) * 4 / 1e9,
+            "how": "chip-filling v_fma_f64 kernel, HIP events, FMA = 2 flops (rtm_debug_fp64_peak; the per-instruction "
+                   "price list of the same method: profiles/r3/fp64_peak.txt)"}
+
+
+# Issue cost of a wave64 VALU instruction per class, in cycles of the SIMD it occupies, from the wall-clock price list
+# of profiles/ubench/fp64_peak.hip (profiles/r3/fp64_peak.txt: ns per wave-instruction per SIMD relative to v_fma_f64 = 4
+# cycles: fp64 add/mul/fma/min/ldexp/compare, v_cndmask_b32 with an SGPR mask, conversions, 64-bit moves, v_mul_lo/hi_u32
+# and v_mad_u64_u32 all cost the same 4; v_mov_b32, v_add_u32, v_xor_b32 and v_fma_f32 cost 2; v_rcp/v_rsq_f64 13.9;
+# v_sqrt_f32 7).  INT32 and "other" are mixes: weights from the static histogram of the hot path
+# (profiles/r2/isa_hotpath_histogram.txt): INT32 = 13 multiplies (4) + 112 add/xor/shift/compare (2) per trip; other =
+# 51 selects + 25 fp64 compares + 12 fix-up/ldexp (4) + 21 moves, mostly 64-bit (4) + 5 lane ops (4).
+VALU_CYCLES = {"SQ_INSTS_VALU_ADD_F64": 4.0, "SQ_INSTS_VALU_MUL_F64": 4.0, "SQ_INSTS_VALU_FMA_F64": 4.0,
+               "SQ_INSTS_VALU_TRANS_F64": 13.9, "SQ_INSTS_VALU_INT32": (13 * 4.0 + 112 * 2.0) / 125, "SQ_INSTS_VALU_INT64": 4.0,
+               "SQ_INSTS_VALU_CVT": 4.0, "SQ_INSTS_VALU_FMA_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_ADD_F32": 2.0,
+               "SQ_INSTS_VALU_TRANS_F32": 7.0, "other": 4.0}
+
+
+def valu_issue_view(pmc, source):
+    """Instruction-issue view of the render kernel from a committed PMC pass of the same command: the hardware's own
+    busy figure (rocprof's derived VALUBusy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / GRBM_GUI_ACTIVE: the SQ cycle counters
+    tick in units of four cycles) and the same from the dynamic mix priced per class with VALU_CYCLES."""
+    cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0  # counter is summed over the 8 XCDs
+    total = pmc["SQ_INSTS_VALU"]
+    classes = {k: pmc.get(k, 0.0) for k in VALU_CYCLES if k != "other"}
+    classes["other"] = total - sum(classes.values())
+    priced_cycles = sum(classes[k] * VALU_CYCLES[k] for k in classes)
+    return {"wave_instructions_per_launch": total, "simds": 1024, "kernel_cycles": cyc,
+            "clock_ghz": cyc / (pmc["kernel_stats"][0]["AverageNs"] if isinstance(pmc["kernel_stats"][0]["AverageNs"], float)
+                                else float(pmc["kernel_stats"][0]["AverageNs"])),
+            "valu_busy_hw": pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc,
+            "valu_busy_priced": priced_cycles / 1024.0 / cyc,
+            "priced_cycles_per_instruction": priced_cycles / total,
+            "class_counts": classes, "class_cycles": VALU_CYCLES,
+            "fp64_arith_share": (classes["SQ_INSTS_VALU_ADD_F64"] + classes["SQ_INSTS_VALU_MUL_F64"] +
+                                 classes["SQ_INSTS_VALU_FMA_F64"] + classes["SQ_INSTS_VALU_TRANS_F64"]) / total,
+            "active_lanes_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / total / 64.0,
+            "wave_wait_share": {"SQ_WAIT_INST_ANY_over_SQ_WAVE_CYCLES": pmc.get("SQ_WAIT_INST_ANY", 0.0) / max(1.0, pmc.get("SQ_WAVE_CYCLES", 1.0)),
+                                "resident_waves_per_simd": pmc.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / 1024.0 / cyc,
+                                "note": "4 resident waves share one VALU that is busy ~all the time, so each wave issues at most a "
+                                        "quarter of the time; about half of a wave's resident time is spent waiting on its own "
+                                        "previous instruction (dependent fp64 chains), the rest ready but not picked"},
+            "measured_in_run": False, "source": source}
+
+
+def other_configs(rtm, cfg, device, host_trig, full_c5=True):
+    """BASELINE configs[1], configs[4] (the full frame unless --no-full-c5, and a strip) and the plane scene, measured in
+    this run, outside the timed region."""
     import torch
     out = {"measured_in_run": True}
     data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
@@ -147,6 +205,24 @@ def other_configs(rtm, cfg, device, host_trig):
         "max_abs_delta": float(delta.max()), "mean_abs_delta": float(delta.mean()),
         "note": "float arithmetic, v_sqrt/v_rsq/v_sin/v_cos, fused multiply-adds, forward throughput: a sample whose ray "
                 "grazes a silhouette may take another path than the reference's; not comparable with the headline value"}
+    # scenes/planeRoom.json (png::PlaneObject completed as a finite square) at 1080p x 256 spp: the chunked
+    # LDS-table kernel with the plane test in its object chunk
+    room = rtm.LoadData(os.path.join(ROOT, "scenes", "planeRoom.json")).data
+    room.width, room.height, room.samples, room.superSamples = 1920, 1080, 16, 4
+    r = rtm.Renderer(room, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
+    r.render_rows_device(want=("f32",), stats=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r.render_rows_device(want=("f32",), stats=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    _, st = r.render_rows_device(want=("f32",), stats=True)
+    out["plane_room_1080p_256spp_max8"] = {
+        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+        "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+        "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"],
+        "note": "6 planes + 2 spheres; not a reference scene (the reference's PlaneObject::Intersect is unfinished)"}
     stress = rtm.make_stress_scene(n=100_000, seed=12345)
     stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
     r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
@@ -162,7 +238,24 @@ def other_configs(rtm, cfg, device, host_trig):
         "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
         "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
         "note": "a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the chip "
-                "(DESIGN.md §4); the full 1080p frame runs at 21.9 Msamples/s (profiles/r2/c5_full_frame_bench.json)"}
+                "(DESIGN.md §4)"}
+    if full_c5:
+        # BASELINE configs[4] as named: the whole 1080p frame at 256 spp, one timed step (~25 s)
+        t0 = time.perf_counter()
+        _, st = r.render_rows_device(want=("f32",), stats=True)
+        dt = time.perf_counter() - t0
+        tests_per_s = st["casts"] * 100_000 / dt
+        row = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
+               "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+               "sphere_tests_per_s": tests_per_s,
+               "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+               "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "traffic": None}
+        tpath = os.path.join(ROOT, "profiles", "r3", "c5_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            row["traffic"] = tj["bytes_per_frame"]
+            row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_traffic.json", "note": tj.get("note")}
+        out["c5_stress_100k_full_1080p_256spp"] = row
     return out
 
 
@@ -223,6 +316,9 @@ def main():
                          "bit-identical either way (tests/test_parity_gpu.py), adversarial scenes are not")
     ap.add_argument("--host-trig", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-extras", action="store_true", help="skip with_d2h and other_configs")
+    ap.add_argument("--no-full-c5", action="store_true",
+                    help="other_configs: skip the full 1080p x 256 spp frame of the 100k-sphere scene (~25 s plus ~25 s of warm-up "
+                         "inside the strip rows); the 64-row strip is still measured")
     ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
                     help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
@@ -447,18 +543,16 @@ def main():
                         "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
-        ppath = next((q for q in (os.path.join(ROOT, "profiles", "r2", "default_pmc_summary.json"),
+        ppath = next((q for q in (os.path.join(ROOT, "profiles", "r3", "default_pmc_summary.json"),
+                                  os.path.join(ROOT, "profiles", "r2", "default_pmc_summary.json"),
                                   os.path.join(ROOT, "profiles", "r1", "default_pmc_summary.json")) if os.path.exists(q)), "")
         if world == 1 and headline and args.variant == 0 and ppath:
-            # instruction-issue view of the same kernel (committed PMC pass of this command): a wave64
-            # fp64 VALU instruction occupies its SIMD for 4 cycles (16 fp64 lanes per SIMD per clock)
-            pmc = json.load(open(ppath))
-            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0  # counter is summed over the 8 XCDs
-            line["roofline"]["valu_issue"] = {
-                "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "simds": 1024, "kernel_cycles": cyc,
-                "busy_frac_if_4_cycles_each": pmc["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc,
-                "active_lanes_frac": pmc.get("SQ_THREAD_CYCLES_VALU", 0.0) / pmc["SQ_INSTS_VALU"] / 64.0,
-                "measured_in_run": False, "source": os.path.relpath(ppath, ROOT)}
+            line["roofline"]["valu_issue"] = valu_issue_view(json.load(open(ppath)), os.path.relpath(ppath, ROOT))
+        if world == 1 and not args.no_extras:
+            pk = measured_fp64_peak(rtm)
+            line["roofline"]["peak_measured"] = pk
+            line["roofline"]["frac_of_measured_peak"] = achieved_tflops / pk["value"]
+            line["roofline"]["peak_source"] = "AMD datasheet, FP64 vector 78.6 TFLOP/s (MI355X_MICROARCH.md lists fp32 157.3 only)"
         if n_spheres >= 512 and args.variant in (0, 12):
             # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
             # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
@@ -484,7 +578,7 @@ def main():
                                 "what": "the same K steps with the gathered frame copied to pinned host memory each step "
                                         "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
         if world == 1 and not args.no_extras and headline:
-            line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig)
+            line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=not args.no_full_c5)
         print(json.dumps(line), flush=True)
     if use_group:
         dog.enter("destroy_process_group")

@@ -192,10 +192,12 @@ size_t rtm_scene_size(const rtm_scene* scene);
  * rtm_render_scene with stats == NULL only ENQUEUES work on `stream` and returns: no copy from pageable
  * memory and no wait — except that the FIRST call on a (device, stream) pair sets up its context, and a call
  * that needs a larger work buffer than the pair has (see rtm_release_scratch) grows it, which allocates and
- * waits for that stream's queued work once; steady-state calls do neither (scenes of 512 spheres or more: the
- * large-scene pipeline is a host loop of launches that follows the device-resident active-pixel
- * count one batch of trips behind; the call returns when the last batch has been enqueued and the
- * count has been seen at zero, i.e. it blocks for about the duration of the render).
+ * waits for that stream's queued work once; steady-state calls do neither.  Scenes of 512 spheres or more run a
+ * pipeline of two launches per ray cast of the slowest pixel: with a depth cap such that samples x superSamples^2 x
+ * (max_bounces + 1) <= 16 384 every trip that could be needed is enqueued at once (those after the last active pixel
+ * has finished fall through) and the call returns like any other; with unlimited depth or a longer budget the host
+ * follows the device-resident active-pixel count one batch of trips behind and the call returns when it has seen the
+ * count at zero, i.e. it blocks for about the duration of the render.
  * With stats != NULL the call synchronises the stream to read the counters and the timing.
  *
  * Hit records of paths deeper than the on-chip levels spill to a pooled buffer (capacity: 976

@@ -25,6 +25,11 @@ int rtm_debug_selfcheck(int kind, unsigned long long* mismatches);
  * in front of the same arithmetic); any other kind is RTM_ERR_INVALID_ARGUMENT */
 int rtm_debug_wf_nearest(int kind, const rtm_sphere* spheres, size_t n, const double* org, const double* dir,
                          size_t n_rays, int32_t* out_id, double* out_t);
+/* the fp64 vector peak of the current device by wall clock: a chip-filling v_fma_f64 kernel (`waves_per_simd` waves on
+ * every SIMD, 8 independent accumulators per lane) timed with HIP events over a launch of at least `min_ms`;
+ * *tflops counts an FMA as 2 flops.  bench.py puts it beside the datasheet figure ("verify by
+ * microbenchmark"); profiles/ubench/fp64_peak.hip is the stand-alone form with the per-instruction price list. */
+int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */
 int rtm_debug_component_bench(int which, const rtm_sphere* spheres, size_t n, int reps, int blocks, int lds_pad,
                               double* cycles_per_rep);

@@ -30,7 +30,8 @@
 #define REP8(x) x x x x x x x x
 
 enum Op { FMA64, ADD64, MUL64, FMA32, PKFMA32, CND64E, CMP64, MOV32, MOV64, ADDU32, XOR32, MULLO, MULHI, MADU64, RCP64, RSQ64,
-          CVT6432, MIN64, LDEXP64, SQRT32, NOPS };
+          CVT6432, MIN64, LDEXP64, SQRT32, NOPS, CND32VCC, CMP64VCC, CMPU32, CMPF32, MIN3U32, BFI32, LSHLADD, FFBL, MAXF32, ADD64S,
+          RSQ32, CNDCMP };
 
 template <int OP>
 __global__ __launch_bounds__(256) void peak_kernel(double* out, unsigned long long* ticks, int iters) {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void peak_kernel(double* out, unsigned long lo
     unsigned u0 = threadIdx.x * 2654435761u + 1, u1 = u0 * 3 + 1, u2 = u0 + 7, u3 = u1 + 9, u4 = u0 ^ 5, u5 = u1 ^ 3, u6 = u0 + 11,
              u7 = u1 + 13, m = 0x9E3779B9u;
     unsigned long long t0 = 0, t1 = 0, r0 = 0, r1 = 0;
-    asm volatile("s_mov_b32 s20, 0x33333333\n s_mov_b32 s21, 0x33333333" ::: "s20", "s21");
+    asm volatile("s_mov_b32 s20, 0x33333333\n s_mov_b32 s21, 0x33333333\n s_mov_b64 vcc, s[20:21]" ::: "s20", "s21", "vcc");
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
 #define A8 "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
 #define F8 "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
@@ -84,6 +85,39 @@ __global__ __launch_bounds__(256) void peak_kernel(double* out, unsigned long lo
         if constexpr (OP == CVT6432) { REP8(asm volatile("v_cvt_f32_f64 %8, %0\n v_cvt_f64_f32 %1, %9\n v_cvt_f32_f64 %10, %2\n v_cvt_f64_f32 %3, %11\n"
                                                          "v_cvt_f32_f64 %9, %4\n v_cvt_f64_f32 %5, %8\n v_cvt_f32_f64 %11, %6\n v_cvt_f64_f32 %7, %10"
                                                          : A8, "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));) }
+        // selects in the VOP2 form (mask in VCC, set once), compares into VCC, 32-bit compares, three-operand integer ops
+        if constexpr (OP == CND32VCC) { REP8(asm volatile(I8("v_cndmask_b32_e32", ", %8, vcc") : U8 : "v"(m) : );) }
+        if constexpr (OP == CMP64VCC) { REP8(asm volatile("v_cmp_lt_f64_e32 vcc, %0, %1\n v_cmp_lt_f64_e32 vcc, %1, %2\n"
+                                                          "v_cmp_lt_f64_e32 vcc, %2, %3\n v_cmp_lt_f64_e32 vcc, %3, %4\n"
+                                                          "v_cmp_lt_f64_e32 vcc, %4, %5\n v_cmp_lt_f64_e32 vcc, %5, %6\n"
+                                                          "v_cmp_lt_f64_e32 vcc, %6, %7\n v_cmp_lt_f64_e32 vcc, %7, %0"
+                                                          :: "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "vcc");) }
+        if constexpr (OP == CMPU32) { REP8(asm volatile("v_cmp_lt_u32_e64 s[22:23], %0, %1\n v_cmp_lt_u32_e64 s[24:25], %1, %2\n"
+                                                        "v_cmp_lt_u32_e64 s[22:23], %2, %3\n v_cmp_lt_u32_e64 s[24:25], %3, %4\n"
+                                                        "v_cmp_lt_u32_e64 s[22:23], %4, %5\n v_cmp_lt_u32_e64 s[24:25], %5, %6\n"
+                                                        "v_cmp_lt_u32_e64 s[22:23], %6, %7\n v_cmp_lt_u32_e64 s[24:25], %7, %0"
+                                                        :: "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7)
+                                                        : "s22", "s23", "s24", "s25");) }
+        if constexpr (OP == CMPF32) { REP8(asm volatile("v_cmp_lt_f32_e64 s[22:23], %0, %1\n v_cmp_lt_f32_e64 s[24:25], %1, %2\n"
+                                                        "v_cmp_lt_f32_e64 s[22:23], %2, %3\n v_cmp_lt_f32_e64 s[24:25], %3, %4\n"
+                                                        "v_cmp_lt_f32_e64 s[22:23], %4, %5\n v_cmp_lt_f32_e64 s[24:25], %5, %6\n"
+                                                        "v_cmp_lt_f32_e64 s[22:23], %6, %7\n v_cmp_lt_f32_e64 s[24:25], %7, %0"
+                                                        :: "v"(f0), "v"(f1), "v"(f2), "v"(f3), "v"(f4), "v"(f5), "v"(f6), "v"(f7)
+                                                        : "s22", "s23", "s24", "s25");) }
+        if constexpr (OP == MIN3U32) { REP8(asm volatile(I8("v_min3_u32", ", %8, %8") : U8 : "v"(m));) }
+        if constexpr (OP == BFI32) { REP8(asm volatile(I8("v_bfi_b32", ", %8, %8") : U8 : "v"(m));) }
+        if constexpr (OP == LSHLADD) { REP8(asm volatile(I8("v_lshl_add_u32", ", 3, %8") : U8 : "v"(m));) }
+        if constexpr (OP == FFBL) { REP8(asm volatile(I8("v_ffbl_b32", "") : U8);) }
+        if constexpr (OP == MAXF32) { REP8(asm volatile(I8("v_max_f32", ", %8") : F8 : "v"(g));) }
+        if constexpr (OP == RSQ32) { REP8(asm volatile(I8("v_rsq_f32", "") : F8);) }
+        // fp64 add with a scalar (SGPR pair) operand, the form the sphere chunk's p = c - o takes
+        if constexpr (OP == ADD64S) { REP8(asm volatile(I8("v_add_f64", ", s[20:21]") : A8);) }
+        // the hit logic's pattern: compare into an SGPR pair, two selects on it
+        if constexpr (OP == CNDCMP) { REP8(asm volatile("v_cmp_lt_f64_e64 s[22:23], %8, %9\n v_cndmask_b32_e64 %0, %0, %1, s[22:23]\n"
+                                                        "v_cndmask_b32_e64 %2, %2, %3, s[22:23]\n v_cmp_lt_f64_e64 s[24:25], %9, %8\n"
+                                                        "v_cndmask_b32_e64 %4, %4, %5, s[24:25]\n v_cndmask_b32_e64 %6, %6, %7, s[24:25]\n"
+                                                        "v_cndmask_b32_e64 %1, %1, %0, s[22:23]\n v_cndmask_b32_e64 %3, %3, %2, s[24:25]"
+                                                        : U8 : "v"(a0), "v"(a1) : "s22", "s23", "s24", "s25");) }
         if constexpr (OP == NOPS) { REP8(asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");) }
     }
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
@@ -174,6 +208,18 @@ int main(int argc, char** argv) {
     rs.push_back(run<MULHI>("v_mul_hi_u32", w, 0, 1, out, ticks));
     rs.push_back(run<MADU64>("v_mad_u64_u32", w, 0, 1, out, ticks));
     rs.push_back(run<SQRT32>("v_sqrt_f32", w, 0, 1, out, ticks));
+    rs.push_back(run<CND32VCC>("v_cndmask_b32_e32 (vcc mask)", w, 0, 1, out, ticks));
+    rs.push_back(run<CNDCMP>("2 v_cmp_f64 + 6 v_cndmask_e64 (per 8)", w, 0, 1, out, ticks));
+    rs.push_back(run<CMP64VCC>("v_cmp_lt_f64_e32 (vcc)", w, 0, 1, out, ticks));
+    rs.push_back(run<CMPU32>("v_cmp_lt_u32_e64 (sgpr pair)", w, 0, 1, out, ticks));
+    rs.push_back(run<CMPF32>("v_cmp_lt_f32_e64 (sgpr pair)", w, 0, 1, out, ticks));
+    rs.push_back(run<MIN3U32>("v_min3_u32", w, 0, 1, out, ticks));
+    rs.push_back(run<BFI32>("v_bfi_b32", w, 0, 1, out, ticks));
+    rs.push_back(run<LSHLADD>("v_lshl_add_u32", w, 0, 1, out, ticks));
+    rs.push_back(run<FFBL>("v_ffbl_b32", w, 0, 1, out, ticks));
+    rs.push_back(run<MAXF32>("v_max_f32", w, 0, 1, out, ticks));
+    rs.push_back(run<RSQ32>("v_rsq_f32", w, 0, 1, out, ticks));
+    rs.push_back(run<ADD64S>("v_add_f64 (sgpr pair operand)", w, 0, 1, out, ticks));
     rs.push_back(run<NOPS>("s_nop 0", w, 0, 1, out, ticks));
     const double fma_ns = rs[0].ns_per_inst;
     std::printf("%-32s %5s %8s %14s %9s %8s %9s %12s %12s\n", "instruction", "w/SIMD", "ms", "inst/s/SIMD", "ns/inst", "rel fma64",

@@ -116,6 +116,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "rtm_debug_math_probe": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtm_debug_selfcheck": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "rtm_debug_fp64_peak": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rtm_debug_wf_nearest": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_void_p]),
     "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,

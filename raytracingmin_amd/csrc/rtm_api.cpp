@@ -117,6 +117,9 @@ int rtm_debug_wf_nearest(int kind, const rtm_sphere* sp, size_t n, const double*
     RTM_GUARD(rtm::wf_nearest_probe(kind, sp, n, org, dir, n_rays, out_id, out_t))
 }
 int rtm_debug_selfcheck(int kind, unsigned long long* mismatches) { RTM_GUARD(rtm::selfcheck(kind, mismatches)) }
+int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms) {
+    RTM_GUARD(rtm::fp64_peak(waves_per_simd, min_ms, tflops, kernel_ms))
+}
 
 int rtm_scene_load_json(const char* path, int literal_loader, rtm_settings* settings,
                         rtm_sphere* spheres, size_t capacity, size_t* n_spheres) {

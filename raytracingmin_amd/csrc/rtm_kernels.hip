@@ -948,6 +948,25 @@ __global__ __launch_bounds__(64) void shade_bench_kernel(SceneView scene, D3 org
 
 // Exhaustive device-side self-checks (return the number of mismatching inputs).
 //   kind 0: sqrtf_fast == sqrtf for every float in [2^-96, FLT_MAX]
+// fp64 vector peak by wall clock (rtm_debug_fp64_peak; the stand-alone profiles/ubench/fp64_peak.hip has the whole
+// price list): every wave runs `iters` x 64 v_fma_f64 over 8 independent accumulators, `waves_per_simd` waves per SIMD
+// on every CU, no memory traffic in the loop.
+__global__ __launch_bounds__(256) void fp64_peak_kernel(double* out, int iters) {
+    double a0 = threadIdx.x * 1.0000001 + 1.5, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6,
+           a7 = a0 + 7;
+    const double b = 1.0000001, c = 0.5;
+    for (int i = 0; i < iters; ++i) {
+#define RTM_FMA8                                                                                                      \
+    asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"  \
+                 "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"    \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                     \
+                 : "v"(b), "v"(c));
+        RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8
+#undef RTM_FMA8
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 __global__ void selfcheck_kernel(int kind, unsigned long long* mismatches) {
     const unsigned stride = gridDim.x * blockDim.x;
     unsigned long long bad = 0;
@@ -2050,13 +2069,20 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
 }
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): nearest / shade launches until the compacted active
-// list is empty.  The active count stays on the device: launches are queued a batch of trips at a time, a
-// batch ends with a stream-ordered copy of the count into a pinned host word, and the host reads the count
-// of batch b-1 only after batch b has been queued behind it — the GPU never waits for the host.  The count
-// never grows, so a grid sized for the last count seen covers the trips queued after it (blocks beyond the
-// live list exit at once), and the batch queued when the zero is finally seen is a handful of empty
-// launches.
-static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx) {
+// list is empty.  The active count stays on the device, and so does everything that depends on it (the number of
+// parts the sphere list is cut into, which blocks of a launch have work); two ways to drive the trips:
+//  * FIXED BUDGET (a depth cap, spp x (max_bounces + 1) <= kWfAsyncTrips): a pixel needs at most max_bounces + 1 casts
+//    per sample and advances one cast per trip, so that many trips finish every frame.  All of them are enqueued at
+//    once, with grids sized for the worst case; a launch whose list is empty falls through in a few microseconds (the
+//    headline stress frame needs ~1 100 of its 2 304 trips: ~10 ms of empty launches behind 24 s of work).  The call
+//    only enqueues — rtm_render_scene's contract for every other scene size.
+//  * FOLLOWING THE COUNT (a call with rtm_stats, which waits anyway; unlimited depth; a budget too long to enqueue
+//    blindly): launches are queued a batch of
+//    trips at a time, a batch ends with a stream-ordered copy of the count into a pinned host word, and the host reads
+//    the count of batch b-1 only after batch b has been queued behind it — the GPU never waits for the host, but the
+//    call returns only when the count has been seen at zero.
+constexpr unsigned long long kWfAsyncTrips = 16384;
+static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, bool may_block) {
     hipStream_t stream = ctx.stream;
     WfState S;
     std::memset(&S, 0, sizeof S);
@@ -2099,7 +2125,6 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx) {
     S.part_t = (double*)take((size_t)(kWfMaxParts - 1) * kWfPartSlots * 8);
     S.part_id = (int*)take((size_t)(kWfMaxParts - 1) * kWfPartSlots * 4);
     S.part_slots = kWfPartSlots;
-    S.parts = 1;
     if (!P.scene.geom32) {
         set_last_error("scene without rejection-test data");
         return RTM_ERR_INVALID_ARGUMENT;
@@ -2107,6 +2132,21 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx) {
     const unsigned grid = (unsigned)((N + 255) / 256);
     wf_init_kernel<<<grid, 256, 0, stream>>>(P, S);  // also sets n_active = {npix, 0}
     RTM_HIP_CHECK(hipGetLastError());
+
+    const unsigned shade_grid = grid;
+    // (a call WITH rtm_stats waits for the stream anyway: it follows the count and skips the empty launches)
+    if (!may_block && P.max_bounces >= 0 &&
+        (unsigned long long)P.total_samples * (unsigned long long)(P.max_bounces + 1) <= kWfAsyncTrips) {
+        const unsigned trips = P.total_samples * (unsigned)(P.max_bounces + 1);
+        const unsigned near_grid = wf_nearest_grid(S.npix, P.scene.n);
+        int cur = 0;
+        for (unsigned t = 0; t < trips; ++t, cur ^= 1) {
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<near_grid, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
+            wf_shade_kernel<<<shade_grid, 256, 0, stream>>>(P, S, cur);
+        }
+        RTM_HIP_CHECK(hipGetLastError());
+        return RTM_OK;
+    }
 
     struct Events {
         hipEvent_t e[2] = {nullptr, nullptr};
@@ -2130,17 +2170,10 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx) {
         // short trips (few spheres or few rays): eight per batch, so that the host's lag of one batch hides the
         // read-back; long trips: one
         const int batch = ((unsigned long long)na * (unsigned long long)P.scene.n < 2000000000ull) ? 8 : 1;
+        const unsigned near_grid = wf_nearest_grid(na, P.scene.n);  // covers every count up to the last one seen
         const unsigned g = (na + 255) / 256;
-        // few rays against a long list: cut the list so that rays x parts fills the chip (~16 waves per SIMD's worth)
-        int parts = 1;
-        while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * parts * 2 <= (1ull << 20) &&
-                   P.scene.n / (parts * 2) >= 2048)
-                parts *= 2;
-        S.parts = parts;
-        S.part_blocks = g;
         for (int k = 0; k < batch; ++k, ++trip) {
-            RTM_HIP_CHECK(hipMemsetAsync(S.n_active + (cur ^ 1), 0, sizeof(unsigned), stream));
-            wf_nearest_f32_kernel<MathFast, 256, 8><<<g * (unsigned)parts, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
+            wf_nearest_f32_kernel<MathFast, 256, 8><<<near_grid, 256, 256 * kWfCandCap * sizeof(unsigned), stream>>>(P, S, cur);
             wf_shade_kernel<<<g, 256, 0, stream>>>(P, S, cur);
             cur ^= 1;
         }
@@ -2359,7 +2392,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         RTM_HIP_CHECK(hipEventRecord(ev.a, stream));
     }
     if (variant == kVariantWavefrontRejectF32) {
-        rc = run_wavefront(P, rows, ctx);
+        rc = run_wavefront(P, rows, ctx, stats != nullptr);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, stream);
@@ -2771,6 +2804,36 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     RTM_HIP_CHECK(hipDeviceSynchronize());
     RTM_HIP_CHECK(hipMemcpy(out_id, S.hit_id, N * 4, hipMemcpyDeviceToHost));
     RTM_HIP_CHECK(hipMemcpy(out_t, S.hit_t, N * 8, hipMemcpyDeviceToHost));
+    return RTM_OK;
+}
+
+int fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms) {
+    if (!tflops || waves_per_simd < 1 || waves_per_simd > 8) return RTM_ERR_INVALID_ARGUMENT;
+    int device = 0, cus = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    RTM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    const int blocks = cus * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+    DevMem out;
+    int rc = out.alloc((size_t)blocks * 256 * sizeof(double));
+    if (rc != RTM_OK) return rc;
+    EventPair ev;
+    if ((rc = ev.create()) != RTM_OK) return rc;
+    int iters = 4000;
+    float ms = 0.f;
+    for (int attempt = 0; attempt < 6; ++attempt) {  // grow until the timed launch is long enough for the clock to settle
+        fp64_peak_kernel<<<blocks, 256>>>(out.as<double>(), iters / 10 + 1);
+        RTM_HIP_CHECK(hipEventRecord(ev.a, nullptr));
+        fp64_peak_kernel<<<blocks, 256>>>(out.as<double>(), iters);
+        RTM_HIP_CHECK(hipEventRecord(ev.b, nullptr));
+        RTM_HIP_CHECK(hipEventSynchronize(ev.b));
+        RTM_HIP_CHECK(hipEventElapsedTime(&ms, ev.a, ev.b));
+        if (ms >= min_ms) break;
+        iters = (int)(iters * (1.2 * min_ms / (ms > 0.05f ? ms : 0.05f))) + 1;
+    }
+    RTM_HIP_CHECK(hipGetLastError());
+    // FMA = 2 flops (the vendor's convention): blocks x 256 lanes x iters x 64 instructions
+    *tflops = 2.0 * (double)blocks * 256.0 * (double)iters * 64.0 / ((double)ms * 1e-3) / 1e12;
+    if (kernel_ms) *kernel_ms = ms;
     return RTM_OK;
 }
 

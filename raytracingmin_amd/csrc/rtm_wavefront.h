@@ -40,13 +40,12 @@ struct WfState {
     unsigned* n_active;  // [2]
     unsigned npix;
     int levels;
-    // Few active rays (a small frame, a strip, the tail of a frame): the sphere list is cut into `parts` ranges and
-    // every range gets its own blocks, so that the chip is filled by rays x ranges instead of idling at one or two
-    // waves per SIMD on a latency-bound scalar stream.  Part 0 writes hit_t / hit_id as always; part q >= 1 writes
-    // slot i of the active list into part_t / part_id[(q - 1) * part_slots + i]; the shade kernel takes the
+    // Few active rays (a small frame, a strip, the tail of a frame): the sphere list is cut into wf_parts(active count)
+    // ranges and every range gets its own blocks, so that the chip is filled by rays x ranges instead of idling at one
+    // or two waves per SIMD on a latency-bound scalar stream.  Part 0 writes hit_t / hit_id as always; part q >= 1
+    // writes slot i of the active list into part_t / part_id[(q - 1) * part_slots + i]; the shade kernel takes the
     // smallest t with strict < in part order — parts ascend in sphere index, so the lowest index still wins ties.
-    int parts;             // 0 or 1: no split
-    unsigned part_blocks;  // blocks per part (rays / 256)
+    // Both kernels derive the number of parts from the DEVICE's active count (the host never has to know it).
     unsigned part_slots;   // capacity of one part's slot arrays
     double* part_t;
     int* part_id;
@@ -54,6 +53,28 @@ struct WfState {
 constexpr int kWfCandCap = 16;               // candidate slots per lane of wf_nearest_f32_kernel (LDS: 4 B x BLOCK each)
 constexpr unsigned kWfPartSlots = 1u << 19;  // the split is used only while the active list is this short
 constexpr int kWfMaxParts = 8;
+// parts of the sphere list for `na` active rays and `n` spheres: doubled while the list is long enough (>= 2048 spheres
+// per part), the rays few enough for the slot arrays, and rays x parts short of ~16 waves per SIMD's worth
+__host__ __device__ inline int wf_parts(unsigned na, int n) {
+    int parts = 1;
+    while (parts < kWfMaxParts && na <= kWfPartSlots && (unsigned long long)na * (unsigned)parts * 2ull <= (1ull << 20) &&
+           n / (parts * 2) >= 2048)
+        parts *= 2;
+    return parts;
+}
+// blocks of 256 rays x parts a nearest-hit launch needs for an active count of AT MOST `na` (the product is not
+// monotonic in the count: fewer rays may mean more parts)
+inline unsigned wf_nearest_grid(unsigned na, int n) {
+    unsigned best = 1;
+    const unsigned cand[4] = {na, na < kWfPartSlots ? na : kWfPartSlots, na < (1u << 19) ? na : (1u << 19), na < (1u << 18) ? na : (1u << 18)};
+    const unsigned cand2 = na < (1u << 17) ? na : (1u << 17);
+    for (unsigned c : {cand[0], cand[1], cand[2], cand[3], cand2}) {
+        if (c == 0) continue;
+        const unsigned g = ((c + 255u) / 256u) * (unsigned)wf_parts(c, n);
+        best = g > best ? g : best;
+    }
+    return best;
+}
 
 __device__ __forceinline__ void wf_pixel_xy(const RenderParams& P, unsigned p, int& x, int& y) {
     x = (int)(p % (unsigned)P.W);
@@ -167,11 +188,17 @@ __global__ __launch_bounds__(256) void wf_scene_aux_kernel(const double4* __rest
 template <class M, int BLOCK, int K, bool PACKED = true>
 __global__ __launch_bounds__(BLOCK) void wf_nearest_f32_kernel(const RenderParams P, const WfState S, const int cur) {
     static_assert(K == 4 || K == 8, "one or two 64-byte scalar loads per chunk");
+    static_assert(BLOCK == 256, "wf_nearest_grid counts blocks of 256 rays");
     const unsigned na = S.n_active[cur];
-    const int parts = S.parts > 1 ? S.parts : 1;
-    const unsigned part = parts > 1 ? blockIdx.x / S.part_blocks : 0u;       // wave-uniform
-    const unsigned ray_block = parts > 1 ? blockIdx.x % S.part_blocks : blockIdx.x;
-    if (ray_block * (unsigned)BLOCK >= na) return;
+    // the NEXT list's count starts at zero: the shade launch behind this one appends to it (the slot was this trip's
+    // predecessor's `cur`, which nothing reads any more)
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.n_active[cur ^ 1] = 0u;
+    if (na == 0u) return;  // the frame is finished: the remaining launches of a fixed trip budget fall through
+    const int parts = wf_parts(na, P.scene.n);
+    const unsigned part_blocks = (na + (unsigned)BLOCK - 1u) / (unsigned)BLOCK;
+    const unsigned part = blockIdx.x / part_blocks;       // wave-uniform
+    const unsigned ray_block = blockIdx.x % part_blocks;
+    if (part >= (unsigned)parts) return;  // the grid is sized for the worst (count, parts) pair
     const unsigned i = ray_block * (unsigned)BLOCK + threadIdx.x;
     const bool live = i < na;
     const unsigned N = S.npix;
@@ -363,7 +390,8 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderParams P, con
         // nearest hit over the parts of the sphere list (one part: what the search wrote)
         int hit_id = S.hit_id[p];
         double hit_t = S.hit_t[p];
-        for (int q = 1; q < S.parts; ++q) {  // wave-uniform count; ascending sphere index, strict <: lowest index wins ties
+        const int parts = wf_parts(na, P.scene.n);
+        for (int q = 1; q < parts; ++q) {  // wave-uniform count; ascending sphere index, strict <: lowest index wins ties
             const int idq = S.part_id[(size_t)(q - 1) * S.part_slots + i];
             const double tq = S.part_t[(size_t)(q - 1) * S.part_slots + i];
             const bool better = idq >= 0 && tq < hit_t;

@@ -1500,3 +1500,43 @@ def test_scene_destroy_and_stream_release_do_not_wait_for_other_work(rtm, oracle
     assert L.rtm_stream_release(0, C.c_void_p(sb.cuda_stream)) == 0
     out2, _ = rsmall.render_rows_device(want=("f64",), stats=True, stream=sb.cuda_stream)   # a fresh context is made
     assert _bits_equal(out2["f64"].cpu().numpy(), ref)
+
+
+def test_large_scene_render_only_enqueues(rtm, oracle):
+    """include/rtm.h: with a depth cap whose trip budget (spp x (max_bounces + 1)) is short enough, a render of a scene of
+    512 spheres or more — the two-launches-per-trip pipeline — only ENQUEUES, like every other size: the call returns
+    while the stream is still busy, a second frame queued behind it is the same frame, and both are the frame of the
+    blocking call (which follows the device's count instead) and of the oracle on spot pixels."""
+    import time
+    import torch
+    data = rtm.make_stress_scene(n=100_000, seed=12345)
+    data.width, data.height, data.samples, data.superSamples = 256, 144, 8, 1
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=77)
+    blocking, st = r.render_rows_device(want=("f64",), stats=True)            # also warms scene + buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a, _ = r.render_rows_device(want=("f64",), stats=False)
+    b, _ = r.render_rows_device(want=("f64",), stats=False)
+    t_enqueue = time.perf_counter() - t0
+    busy = not torch.cuda.current_stream().query()
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    r.stream_status()
+    print(f"two 100k-sphere frames: enqueued in {t_enqueue * 1e3:.1f} ms, finished after {t_total * 1e3:.1f} ms "
+          f"(one blocking frame: {st['kernel_ms']:.1f} ms of kernels)")
+    assert busy and t_enqueue < 0.5 * t_total
+    assert torch.equal(a["f64"], blocking["f64"]) and torch.equal(b["f64"], blocking["f64"])
+    ost, oarr, n = _oracle_view(oracle, data)
+    rng = np.random.default_rng(3)
+    px = np.stack([rng.integers(0, 256, 12), rng.integers(0, 144, 12)], axis=1)
+    ref, _ = oracle.render_pixels(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=77, height=144), px)
+    got = a["f64"].cpu().numpy()
+    for k, (x, y) in enumerate(px):
+        assert _bits_equal(got[y, x], ref[k]), (x, y)
+    # unlimited depth: no budget can be known, the call follows the count (blocks) — and is still the oracle's frame
+    ru = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=77)
+    u, _ = ru.render_rows_device(0, 16, want=("f64",), stats=False)
+    refu, _ = oracle.render_pixels(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=77, height=144),
+                                   np.array([[5, 3], [200, 9]]))
+    gu = u["f64"].cpu().numpy()
+    assert _bits_equal(gu[3, 5], refu[0]) and _bits_equal(gu[9, 200], refu[1])
