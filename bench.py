@@ -328,7 +328,7 @@ def main():
                          "every step goes through the gather")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--stage-timeout", type=float, default=120.0,
+    ap.add_argument("--stage-timeout", type=float, default=300.0,
                     help="seconds a start-up / collective stage may take before the rank exits with code 3 naming it "
                          "(render stages get 10x this)")
     ap.add_argument("--launch-check", action="store_true",
@@ -344,7 +344,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     from raytracingmin_amd.distributed import StageWatchdog
     dog = StageWatchdog(limit_s=args.stage_timeout, rank=rank, quiet=(world == 1 and args.backend is None))
-    dog.enter("import torch")
+    dog.enter("import torch", max(600.0, args.stage_timeout))  # a fresh box pages the image in: minutes, with 8 ranks at once
     import torch
     import torch.distributed as dist
     import raytracingmin_amd as rtm

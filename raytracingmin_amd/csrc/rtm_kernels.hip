@@ -73,8 +73,11 @@ struct RenderParams {
     // idle one after another.  n_tiles counts the split tiles; their blocks follow the whole tiles' in the grid.
     unsigned n_tiles, split, split_head, split_len, split_first;
     double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_head samples
-    double* __restrict__ contrib;  // [tile][total_samples - split_head][3][64]: per-sample terms of waves 1..
+    // per-sample terms of waves 1..: one block of split_len rows per (tile, small wave), a row = 64 terms in the order
+    // the wave FOLDED them ([3][64] doubles, whole lines from one store instruction) + 64 tags (owner lane, sample)
+    unsigned char* __restrict__ contrib;
 };
+constexpr size_t kTermRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned short);  // 1664 = 13 lines of 128 B
 
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -229,6 +232,7 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
 constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
 constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
+constexpr size_t kFoldTagBytes = kFoldRing * sizeof(unsigned short);            // SPLIT: (owner lane, sample) of the entries
 
 //   PLANES  (with LDS_TAB) the scene holds png::PlaneObject entries: SceneLdsObjects / object_chunk / MathSpecZ
 //           (rtm_path.h) — a plane's test in its index slot of the chunk, its normal from the LDS table
@@ -237,6 +241,7 @@ template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE =
           bool REUSE = false, bool PLANES = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
     static_assert(!PLANES || (LDS_TAB && !REUSE), "plane scenes ride on the LDS tables");
+    static_assert(!SPLIT || DEFER, "the sample split's small waves store their terms from the fold queue");
     static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
     static_assert(!REUSE || (DEFER && PACK8 && !SPLIT), "primary-hit reuse rides on the deferred fold with packed records");
     static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
@@ -256,6 +261,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
     unsigned long long* fq_in1 = reinterpret_cast<unsigned long long*>(fq_pend + 64);  // PACKL: word 1 of the entries
     unsigned long long* rec_w1 = fq_in1 + kFoldRing;                                   // PACKL: word 1 of the lanes
+    // SPLIT: tag of every ring entry, behind whatever the record mode needs
+    unsigned short* fq_tag = PACKL ? reinterpret_cast<unsigned short*>(rec_w1 + 64) : reinterpret_cast<unsigned short*>(fq_pend + 64);
     if constexpr (DEFER) fq_pend[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
     if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
@@ -320,10 +327,31 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
     const bool whole = !SPLIT || blockIdx.x < P.split_first;  // this wave traces all samples of its tile
-    const unsigned split_f = whole ? 0u : (blockIdx.x - P.split_first) / P.n_tiles;
-    const unsigned split_tile = whole ? 0u : (blockIdx.x - P.split_first) % P.n_tiles;  // index into partial / contrib
-    const unsigned n_first = (SPLIT && split_f != 0) ? P.split_head + (split_f - 1u) * P.split_len : 0u;
-    const unsigned n_end = whole ? P.total_samples : (split_f != 0 ? n_first + P.split_len : P.split_head);
+    // Which wave of a split tile this is, recomputed from an OPAQUE copy of the block index wherever it is needed (a
+    // small wave's fold passes, the head wave's final store): kept live across the render loop, these scalars pushed
+    // hipcc over its SGPR budget and it spilled loop-carried scalars to VGPR lanes (27 v_readlane / v_writelane more in
+    // the kernel: +1 % on the headline frame, profiles/r3/ab_r2_vs_r3.txt).
+    auto split_wave = [&](unsigned& f, unsigned& tile) {
+        unsigned b = blockIdx.x;
+        asm volatile("" : "+s"(b));
+        f = (b - P.split_first) / P.n_tiles;
+        tile = (b - P.split_first) % P.n_tiles;  // index into partial / contrib
+    };
+    unsigned n_first = 0u, n_end = P.total_samples;
+    if (!whole) {
+        unsigned f, tile;
+        split_wave(f, tile);
+        n_first = f != 0u ? P.split_head + (f - 1u) * P.split_len : 0u;
+        n_end = f != 0u ? n_first + P.split_len : P.split_head;
+    }
+    // a SMALL wave of the sample split (wave-uniform; its first sample is never 0: wave 0 keeps at least one share):
+    // it accumulates nothing — every term goes to P.contrib in the order the wave folds them, 64 to a row, and
+    // split_finalize_kernel puts each pixel's terms back in sample order
+    // The render loop is compiled TWICE into a SPLIT kernel (`trace` below, generic over a compile-time tag) and a wave
+    // picks its copy once: a whole or head wave runs exactly the loop of the unsplit kernel, a small wave a loop without
+    // the per-lane FIFO.  One copy with wave-uniform "am I small" branches cost every whole wave of a split launch 1 %
+    // (profiles/r3/ab_r2_vs_r3.txt: 181.1 against round 2's 179.3 ms with 64 split tiles).
+    unsigned terms_out = 0;  // terms this small wave has stored (wave-uniform)
     unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
     int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
     const int sub_first = (int)(n_first / (unsigned)P.S);
@@ -363,7 +391,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     // DEFER: ring indices (wave-uniform) and one pass of the queue
     unsigned fq_head = 0, fq_tail = 0, fq_count = 0;
-    auto fold_pass = [&]() {
+    auto fold_pass = [&](auto small_tag) {
+        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
         const unsigned m = fq_count < 64u ? fq_count : 64u;
         if ((unsigned)lane < m) {
             const unsigned at = (fq_head + (unsigned)lane) & (kFoldRing - 1);
@@ -377,41 +406,55 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 L = path_fold_packed8_all(sc, (int)e.z, w0);
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;  // :240
             const D3 add = clamp01_d3(cal);
-            fq_out[0 * 64 + lane] = add.x;
-            fq_out[1 * 64 + lane] = add.y;
-            fq_out[2 * 64 + lane] = add.z;
+            if constexpr (SMALL) {
+                // Whole lines from one instruction: the 64 folding lanes write their terms back to back (three 512-byte
+                // rows) with the entry's tag behind them.  Round 2 let every OWNER store its term into a [sample][lane]
+                // cell: 32-byte stores scattered over the tile's buffer, each completed to the memory's 64-byte granule by
+                // a read (PMC: 4.5 GB fetched + 1.6 GB written per headline launch for 1.2 GB of terms).
+                unsigned sf, stile;
+                split_wave(sf, stile);
+                unsigned char* term_rows = P.contrib + ((size_t)stile * (P.split - 1u) + (sf - 1u)) * P.split_len * kTermRowBytes;
+                const unsigned pos = terms_out + (unsigned)lane;
+                unsigned char* row = term_rows + (size_t)(pos >> 6) * kTermRowBytes;
+                double* v = reinterpret_cast<double*>(row) + (pos & 63u);
+                // NON-TEMPORAL stores: a plain store of a whole 512-byte row still made L2 fetch the lines it was about to
+                // overwrite (PMC, profiles/r3/term_store_modes.txt: 1.25 GB fetched in the render kernel against 0.48 with
+                // `nt`; 16-byte-per-lane stores through LDS changed nothing)
+                __builtin_nontemporal_store(add.x, v);
+                __builtin_nontemporal_store(add.y, v + 64);
+                __builtin_nontemporal_store(add.z, v + 128);
+                __builtin_nontemporal_store(fq_tag[at], reinterpret_cast<unsigned short*>(row + 3 * 64 * sizeof(double)) + (pos & 63u));
+            } else {
+                fq_out[0 * 64 + lane] = add.x;
+                fq_out[1 * 64 + lane] = add.y;
+                fq_out[2 * 64 + lane] = add.z;
+            }
         }
-        // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
-        for (;;) {
-            const unsigned pend = fq_pend[lane] & 0xFFu;  // (PACKL: bit 8 = "a deep entry of this lane may be waiting")
-            const unsigned oldest = (unsigned)(fq_fifo[lane] >> (8u * ((pend ? pend : 1u) - 1u))) & 0xFFu;
-            const unsigned rel = (oldest - fq_head) & (kFoldRing - 1);
-            const bool mine = pend != 0u && rel < m;
-            if (__builtin_amdgcn_ballot_w64(mine) == 0) break;
-            if (mine) {
-                if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
-                    // One 32-byte cell per (sample, lane), layout [tile][sample][lane]: an aligned sector per store.  The 8-byte
-                    // stores into three 512-byte rows of round 1 were read-modify-written (PMC: 11.0 GB fetched and 8.8 GB
-                    // written for 3.2 GB of terms).  Measured (profiles/r2/split_layouts.txt): writes are now exactly the 4.2 GB
-                    // stored, fetches fell from 11.0 to 7.9 GB — stores leave L2 as they come, so a 32-byte store is still
-                    // completed to the memory's 64-byte granule there; [tile][lane][sample] (a lane's samples adjacent) was
-                    // no better (8.5 GB).  Only whole-line stores by one instruction would end that (entries written in
-                    // fold order by the folding lanes, reordered by the finalize kernel): not built, the kernel is not
-                    // bound by this traffic (~0.6 TB/s).
-                    double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)split_tile * (P.total_samples - P.split_head) * 64;
-                    const unsigned s_rel = (n - pend) - P.split_head;  // n - pend: this entry's sample
-                    cells[(size_t)s_rel * 64 + lane] = double4{fq_out[0 * 64 + rel], fq_out[1 * 64 + rel], fq_out[2 * 64 + rel], 0.0};
-                } else {
+        if constexpr (SMALL) {
+            terms_out += m;
+        } else {
+            // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
+            for (;;) {
+                const unsigned pend = fq_pend[lane] & 0xFFu;  // (PACKL: bit 8 = "a deep entry of this lane may be waiting")
+                const unsigned oldest = (unsigned)(fq_fifo[lane] >> (8u * ((pend ? pend : 1u) - 1u))) & 0xFFu;
+                const unsigned rel = (oldest - fq_head) & (kFoldRing - 1);
+                const bool mine = pend != 0u && rel < m;
+                if (__builtin_amdgcn_ballot_w64(mine) == 0) break;
+                if (mine) {
                     park[0 * 64 + lane] += fq_out[0 * 64 + rel];
                     park[1 * 64 + lane] += fq_out[1 * 64 + rel];
                     park[2 * 64 + lane] += fq_out[2 * 64 + rel];
+                    // (the last of the lane's entries: the deep flag goes too; otherwise it stays)
+                    fq_pend[lane] = pend == 1u ? 0u : (fq_pend[lane] - 1u);
                 }
-                // (the last of the lane's entries: the deep flag goes too; otherwise it stays)
-                fq_pend[lane] = pend == 1u ? 0u : (fq_pend[lane] - 1u);
             }
         }
         fq_head = (fq_head + m) & (kFoldRing - 1);
         fq_count -= m;
+        // a small wave's queue has run empty: none of its lanes has an entry waiting, deep or not
+        if constexpr (SMALL) {
+            if (fq_count == 0u) fq_pend[lane] = 0u;
+        }
     };
 
     (void)fold_pass;
@@ -488,7 +531,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     fq_tail = (fq_tail + added) & (kFoldRing - 1);
                     fq_count += added;
                     const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;
-                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass();
+                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(std::false_type{});
                 }
             }
             // ---- bounce: every lane holds a hit that passed the roulette (lanes out of samples: a dummy) ----
@@ -516,9 +559,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             rng.ctr = o.ctr;
             have_fresh_rays = true;
         }
-        while (fq_count > 0u) fold_pass();
+        while (fq_count > 0u) fold_pass(std::false_type{});
     }
     if constexpr (DEFER && !REUSE) {
+      auto trace = [&](auto small_tag) {
+        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
         // Wave-uniform loop: fold_pass needs all 64 lanes whatever their own state, so a lane that has finished
         // its samples cannot leave.  It does not idle either: it keeps tracing (samples beyond its range, results
         // discarded — `live` gates the queue, the counters and nothing else), which costs nothing — the lanes are
@@ -561,10 +606,14 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     } else {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
                     }
+                    if constexpr (SPLIT) {
+                        if constexpr (SMALL) fq_tag[pos] = (unsigned short)((unsigned)lane | ((n - n_first) << 6));
+                    }
+                    // (a small wave never picks its terms up again: its per-lane FIFO only tracks the deep-entry flag)
                     const unsigned pend_word = fq_pend[lane];  // count, and (PACKL) bit 8: a deep entry may be waiting
-                    const unsigned pend = (pend_word & 0xFFu) + 1u;
-                    fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
-                    fifo_full = pend >= 8u;
+                    const unsigned pend = SMALL ? 1u : (pend_word & 0xFFu) + 1u;
+                    if constexpr (!SMALL) fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
+                    fifo_full = !SMALL && pend >= 8u;
                     const bool deep_now = PACKL && depth > 16;
                     fq_pend[lane] = pend | (pend_word & 0x100u) | (deep_now ? 0x100u : 0u);
                     if constexpr (PACKL) {
@@ -607,10 +656,17 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 fq_tail = (fq_tail + added) & (kFoldRing - 1);
                 fq_count += added;
                 const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;  // a lane's FIFO holds 8 positions
-                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass();
+                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(small_tag);
             }
         }
-        while (fq_count > 0u) fold_pass();
+        while (fq_count > 0u) fold_pass(small_tag);
+      };
+      if constexpr (SPLIT) {
+          if (n_first != 0u) trace(std::true_type{});  // (a small wave's first sample is never 0: wave 0 keeps at least one share)
+          else trace(std::false_type{});
+      } else {
+          trace(std::false_type{});
+      }
     }
     unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
     while (!DEFER && n < n_end) {
@@ -646,10 +702,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             // power-of-two divisors are applied as multiplications.
             const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
             const D3 add = clamp01_d3(cal);
-            if (SPLIT && split_f != 0) {  // wave-uniform: keep the term, split_finalize_kernel adds it
-                double4* cells = reinterpret_cast<double4*>(P.contrib) + (size_t)split_tile * (P.total_samples - P.split_head) * 64;
-                cells[(size_t)(n - P.split_head) * 64 + lane] = double4{add.x, add.y, add.z, 0.0};
-            } else if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
+            if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
                 park[0 * 64 + lane] += add.x;
                 park[1 * 64 + lane] += add.y;
                 park[2 * 64 + lane] += add.z;
@@ -702,7 +755,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         int px, py;
         pixel_xy(px, py);
         store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
-    } else if (split_f == 0) {
+    } else if (n_first == 0u) {  // the head wave of a split tile
+        unsigned hf, split_tile;
+        split_wave(hf, split_tile);
         double* dst = P.partial + (size_t)split_tile * 192 + lane;
         dst[0] = acc.x;
         dst[64] = acc.y;
@@ -724,31 +779,46 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 }
 
-// Second half of a SPLIT render: image[pixel] = (((partial + term[split_head]) + term[split_head+1]) + ...),
-// the accumulation order of src/Renderer.cpp:241-242.  One wave per tile; the loads are 2-KB rows of 32-byte cells
-// (one per lane), independent of the adds.
-__global__ __launch_bounds__(64) void split_finalize_kernel(const RenderParams P) {
-    const int lane = threadIdx.x;
+// Second half of a SPLIT render: image[pixel] = (((partial + term[split_head]) + term[split_head+1]) + ...), the
+// accumulation order of src/Renderer.cpp:241-242.  One workgroup of four waves per split tile.  The small waves left
+// their terms in FOLD order (render_tiles_kernel: rows of 64 terms + tags); for one small wave at a time the block
+// scatters its rows into LDS by (sample, owner lane) — the tag — and waves 0..2 then add, each for ONE colour channel
+// (the three sums are independent), their pixel's terms in sample order.  LDS: split_len x 64 x 3 doubles (96 KB at
+// the 64 samples a small wave traces at most).
+__global__ __launch_bounds__(256) void split_finalize_kernel(const RenderParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* slot = reinterpret_cast<double*>(lds_raw);  // [channel][sample][lane]
+    const int tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const unsigned tile = P.split_first + blockIdx.x;  // blockIdx.x: index among the split tiles
-    const double* part = P.partial + (size_t)blockIdx.x * 192 + lane;
-    D3 acc = d3(part[0], part[64], part[128]);
-    const unsigned ns = P.total_samples - P.split_head;
-    const double4* cells = reinterpret_cast<const double4*>(P.contrib) + (size_t)blockIdx.x * ns * 64 + lane;
-    unsigned m = 0;
-    for (; m + 8 <= ns; m += 8) {
-        double4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = cells[(size_t)(m + k) * 64];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc = acc + d3(v[k].x, v[k].y, v[k].z);
-    }
-    for (; m < ns; ++m) {
-        const double4 v = cells[(size_t)m * 64];
-        acc = acc + d3(v.x, v.y, v.z);
-    }
     const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     const int px = tx * 8 + (lane & 7), py = band_row(P, ty, lane >> 3);
-    store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
+    const bool valid = (px < P.W) && (py < P.row_end);
+    // terms a small wave of this tile has stored: one per valid pixel and sample of its range
+    const unsigned n_valid = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
+    const unsigned n_terms = n_valid * P.split_len;
+    const unsigned plane_sz = P.split_len * 64u;  // doubles per channel
+    double acc = chan < 3 ? P.partial[(size_t)blockIdx.x * 192 + chan * 64 + lane] : 0.0;
+    for (unsigned f = 1; f < P.split; ++f) {
+        const unsigned char* rows = P.contrib + ((size_t)blockIdx.x * (P.split - 1u) + (f - 1u)) * P.split_len * kTermRowBytes;
+        for (unsigned e = (unsigned)tid; e < n_terms; e += 256u) {
+            const unsigned char* row = rows + (size_t)(e >> 6) * kTermRowBytes;
+            const double* v = reinterpret_cast<const double*>(row) + (e & 63u);
+            const unsigned tag = reinterpret_cast<const unsigned short*>(row + 3 * 64 * sizeof(double))[e & 63u];
+            const unsigned at = (tag >> 6) * 64u + (tag & 63u);  // [sample][owner lane]
+            slot[at] = v[0];
+            slot[plane_sz + at] = v[64];
+            slot[2 * plane_sz + at] = v[128];
+        }
+        __syncthreads();
+        if (chan < 3) {
+            const double* mine = slot + (size_t)chan * plane_sz + lane;
+            for (unsigned m = 0; m < P.split_len; ++m) acc = acc + mine[m * 64u];  // (an invalid pixel adds stale LDS: never stored)
+        }
+        __syncthreads();
+    }
+    if (chan < 3) slot[chan * 64 + lane] = acc;
+    __syncthreads();
+    if (chan == 0) store_pixel(P, valid, px, py, d3(slot[lane], slot[64 + lane], slot[128 + lane]));
 }
 
 }  // namespace rtm
@@ -1725,19 +1795,20 @@ static size_t debug_lds_pad() {
 template <bool SPLIT>
 static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
+    constexpr size_t tag = SPLIT ? kFoldTagBytes : 0;
     if (P.max_bounces >= 0 && P.max_bounces <= 8)
         render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
-            <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
+            <<<grid, 64, tab + kFoldQueueBytes + tag, stream>>>(P);
     else
         render_tiles_kernel<MathFast, true, 8, uint8_t, 0, 4, true, false, false, SPLIT, true, true, false, true>
-            <<<grid, 64, tab + kFoldQueueBytesL, stream>>>(P);
+            <<<grid, 64, tab + kFoldQueueBytesL + tag, stream>>>(P);
 }
 
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
           bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
-                       (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad();
+                       (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad() + (SPLIT ? kFoldTagBytes : 0);
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
         if (P.max_bounces >= 0 && P.max_bounces <= 8 && P.scene.n < 256) {  // ids and the identity index in a byte
@@ -1758,7 +1829,7 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>
                     <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
             else
-                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT><<<grid, 64, tab, stream>>>(P);
+                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, false><<<grid, 64, tab, stream>>>(P);  // (never split: the split rides on the fold queue)
             return;
         }
     }
@@ -1770,10 +1841,10 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
         }
     }
     if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, false, SPLIT>
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, false, false>
             <<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
     else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP, false, SPLIT>
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP, false, false>
             <<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
 }
 
@@ -1791,7 +1862,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
             if (P.scene.plane != nullptr) {  // render_view: n <= kLdsTableMaxSpheres (ids and the identity index in a byte: n < 256)
                 if (P.split > 1) {
                     launch_render_planes<true>(P, split_grid, stream);
-                    split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+                    split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
                 } else {
                     launch_render_planes<false>(P, grid, stream);
                 }
@@ -1800,7 +1871,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
             if (P.split > 1) {
                 if (n < 8) launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
                 else launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
-                split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+                split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
             } else if (n < 8) {
                 launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
             } else {
@@ -1810,7 +1881,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
         case kVariantGlobalDefer:  // render_view: n < 256
             if (P.split > 1) {
                 launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, true, true>(P, split_grid, stream);
-                split_finalize_kernel<<<P.n_tiles, 64, 0, stream>>>(P);
+                split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
             } else {
                 launch_render_depth<MathFast, false, 8, uint8_t, 4, true, false, true, false, true>(P, grid, stream);
             }
@@ -2033,7 +2104,9 @@ int release_scratch(int device) {
 struct SplitPlan {
     unsigned g;      // granularity: small waves trace 1/g of a pixel's samples (1: no split)
     unsigned tiles;  // how many of the launch's LAST tiles are split
+    unsigned head;   // samples wave 0 of a split tile keeps (a multiple of total / g)
 };
+constexpr unsigned kSplitMaxLen = 64;  // samples per small wave: split_finalize_kernel sorts one small wave's terms in LDS (1.5 KB per sample)
 static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int device, bool forced) {
     static const long env = [] {
         const char* e = std::getenv("RTM_DEBUG_SPLIT");  // tuning knob: 1 = never split, g = every tile with that granularity
@@ -2046,26 +2119,41 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const unsigned slots = (unsigned)cus * 16u;
+    const SplitPlan none{1u, 0u, total_samples};
+    // wave 0 keeps half of the samples (its terms never leave the chip, and it starts in the launch's first rounds, so
+    // the small waves still set the tail: profiles/r2/tail_split.txt, h = 8 of 16); an odd g: the larger half
+    auto head_of = [&](unsigned g) { return g >= 4 ? (total_samples / g) * ((g + 1u) / 2u) : total_samples / g; };
+    auto valid_g = [&](unsigned g) {
+        return g >= 2 && total_samples % g == 0 && total_samples / g >= 8 && total_samples / g <= kSplitMaxLen;
+    };
+    // a small wave traces 1/16 of a pixel's samples (profiles/r1/band_split_sweep_final.json), at least 8 and at most
+    // kSplitMaxLen of them: the divisor of the sample count nearest to that from below, else from above
+    auto pick_g = [&]() -> unsigned {
+        unsigned want = total_samples / 16u;
+        want = want < 8u ? 8u : (want > kSplitMaxLen ? kSplitMaxLen : want);
+        for (unsigned len = want; len >= 8u; --len)
+            if (total_samples % len == 0 && valid_g(total_samples / len)) return total_samples / len;
+        for (unsigned len = want + 1u; len <= kSplitMaxLen; ++len)
+            if (total_samples % len == 0 && valid_g(total_samples / len)) return total_samples / len;
+        return 1u;
+    };
+    // the terms of the split tiles: a 1 664-byte row per (tile, deferred sample), at most 24 GiB per stream
     auto fits = [&](unsigned g, unsigned tiles) {
-        if (g < 2 || total_samples % g != 0 || total_samples / g < 8) return false;
-        const unsigned head = g >= 4 ? total_samples / 2 : total_samples / g;
-        const double per_tile = (double)(total_samples - head) * 2048.0;  // 64 lanes x 32-byte cells per deferred sample
-        return (double)tiles * per_tile <= 24.0 * 1024 * 1024 * 1024 && per_tile < 4.0e9;
+        return (double)tiles * (double)(total_samples - head_of(g)) * (double)kTermRowBytes <= 24.0 * 1024 * 1024 * 1024;
     };
-    auto finest = [&](unsigned tiles) {
-        unsigned g = 1;
-        while (g < 16u && fits(g * 2, tiles)) g *= 2;
-        return g;
-    };
-    if (env > 0) return (env > 1 && fits((unsigned)env, n_tiles)) ? SplitPlan{(unsigned)env, n_tiles} : SplitPlan{1u, 0u};
+    if (env > 0) {
+        const unsigned g = (unsigned)env;
+        return (env > 1 && valid_g(g) && fits(g, n_tiles)) ? SplitPlan{g, n_tiles, head_of(g)} : none;
+    }
+    const unsigned g = pick_g();
+    if (g <= 1u) return none;
+    // the last 3/8 of a round of tiles (1 536 on this chip; profiles/r2/tail_split.txt).  1 024 would keep the launch's term
+    // traffic under 2 GB (profiles/r3/term_store_modes.txt) but costs the headline frame 0.5 % and a one-round launch like
+    // 512 x 512 x 256 spp 17 % (8.0 against 6.9 ms: there the slowest WHOLE tile sets the time; profiles/r3/ab_r2_vs_r3.txt)
     unsigned tail = forced ? n_tiles : env_tail >= 0 ? (unsigned)env_tail : 3u * slots / 8u;
     if (tail > n_tiles) tail = n_tiles;
-    unsigned g = tail ? finest(tail) : 1u;
-    while (g <= 1u && tail > 64u && !forced) {  // many samples per pixel: a shorter tail whose terms fit
-        tail /= 2u;
-        g = finest(tail);
-    }
-    return g > 1 ? SplitPlan{g, tail} : SplitPlan{1u, 0u};
+    while (tail > 64u && !forced && !fits(g, tail)) tail /= 2u;  // very many samples per pixel: a shorter tail whose terms fit
+    return (tail > 0u && fits(g, tail)) ? SplitPlan{g, tail, head_of(g)} : none;
 }
 
 // Wavefront pipeline for large scenes (rtm_wavefront.h): nearest / shade launches until the compacted active
@@ -2340,18 +2428,15 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         if (P.split > 1) {
             P.n_tiles = plan.tiles;
             P.split_first = grid - plan.tiles;
-            // choose_split gives the granularity (1/f of a pixel's samples per small wave).  Wave 0 takes half
-            // of the samples when f >= 4: its terms never leave the chip, which halves the term traffic
-            // (7/8 -> 1/2 of the samples at f = 8), and it starts in the first round, so the small waves
-            // still set the tail.
             P.split_len = P.total_samples / P.split;
-            P.split_head = P.split >= 4 ? P.total_samples / 2 : P.split_len;
+            P.split_head = plan.head;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
-            const size_t part = (size_t)P.n_tiles * 192, terms = (size_t)P.n_tiles * (P.total_samples - P.split_head) * 256;
-            rc = scratch_acquire(ctx, kScratchTerms, (part + terms) * sizeof(double), (void**)&split_ws);
+            const size_t part = (size_t)P.n_tiles * 192 * sizeof(double);
+            const size_t terms = (size_t)P.n_tiles * (P.total_samples - P.split_head) * kTermRowBytes;  // a row per (tile, sample)
+            rc = scratch_acquire(ctx, kScratchTerms, part + terms, (void**)&split_ws);
             if (rc == RTM_OK) {
                 P.partial = split_ws;
-                P.contrib = split_ws + part;
+                P.contrib = reinterpret_cast<unsigned char*>(split_ws) + part;
             } else {  // no room for the terms: the launch runs unsplit (same image, a longer tail) instead of failing
                 (void)hipGetLastError();
                 P.split = 1;

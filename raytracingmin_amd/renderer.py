@@ -10,6 +10,7 @@ behind rtm_render_device.  There is no CPU fallback.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -64,7 +65,6 @@ class Renderer:
             self._scene = None
 
     def __del__(self):
-        import sys
         if sys.is_finalizing():  # interpreter shutdown: the HIP runtime may be gone already; the process's memory goes with it
             return
         try:
