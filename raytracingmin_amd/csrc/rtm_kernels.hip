@@ -232,7 +232,10 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
 constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
 constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
-constexpr size_t kFoldTagBytes = kFoldRing * sizeof(unsigned short);            // SPLIT: (owner lane, sample) of the entries
+// (SPLIT: a small wave's ring entries carry a 2-byte tag (owner lane, sample).  The tags live in the per-lane FIFO array,
+// which a small wave does not use: 256 of its 512 bytes.  A separate array put the any-depth kernel at 10 328 bytes of LDS per
+// wave — 15 instead of 16 waves per CU, 5 % on every unlimited-depth frame, profiles/r3/ab_r2_vs_r3.txt.)
+constexpr size_t kFoldTagBytes = 0;
 
 //   PLANES  (with LDS_TAB) the scene holds png::PlaneObject entries: SceneLdsObjects / object_chunk / MathSpecZ
 //           (rtm_path.h) — a plane's test in its index slot of the chunk, its normal from the LDS table
@@ -261,8 +264,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
     unsigned long long* fq_in1 = reinterpret_cast<unsigned long long*>(fq_pend + 64);  // PACKL: word 1 of the entries
     unsigned long long* rec_w1 = fq_in1 + kFoldRing;                                   // PACKL: word 1 of the lanes
-    // SPLIT: tag of every ring entry, behind whatever the record mode needs
-    unsigned short* fq_tag = PACKL ? reinterpret_cast<unsigned short*>(rec_w1 + 64) : reinterpret_cast<unsigned short*>(fq_pend + 64);
+    // SPLIT, small waves only: tag of every ring entry, in the FIFO array they have no other use for
+    unsigned short* fq_tag = reinterpret_cast<unsigned short*>(fq_fifo);
+    static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
     if constexpr (DEFER) fq_pend[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
     if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
@@ -423,7 +427,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 __builtin_nontemporal_store(add.x, v);
                 __builtin_nontemporal_store(add.y, v + 64);
                 __builtin_nontemporal_store(add.z, v + 128);
-                __builtin_nontemporal_store(fq_tag[at], reinterpret_cast<unsigned short*>(row + 3 * 64 * sizeof(double)) + (pos & 63u));
+                const unsigned tag = fq_tag[at];
+                __builtin_nontemporal_store((unsigned short)tag, reinterpret_cast<unsigned short*>(row + 3 * 64 * sizeof(double)) + (pos & 63u));
+                if constexpr (PACKL) {
+                    // this entry's levels from 16 up have just been read from its owner's pooled stack: one deep entry fewer
+                    // of that lane is waiting (two folding lanes may serve the same owner in one pass: an LDS atomic)
+                    if ((e.z >> 8) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
+                }
             } else {
                 fq_out[0 * 64 + lane] = add.x;
                 fq_out[1 * 64 + lane] = add.y;
@@ -452,9 +462,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         fq_head = (fq_head + m) & (kFoldRing - 1);
         fq_count -= m;
         // a small wave's queue has run empty: none of its lanes has an entry waiting, deep or not
-        if constexpr (SMALL) {
-            if (fq_count == 0u) fq_pend[lane] = 0u;
-        }
+        (void)small_tag;
     };
 
     (void)fold_pass;
@@ -609,13 +617,19 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     if constexpr (SPLIT) {
                         if constexpr (SMALL) fq_tag[pos] = (unsigned short)((unsigned)lane | ((n - n_first) << 6));
                     }
-                    // (a small wave never picks its terms up again: its per-lane FIFO only tracks the deep-entry flag)
-                    const unsigned pend_word = fq_pend[lane];  // count, and (PACKL) bit 8: a deep entry may be waiting
-                    const unsigned pend = SMALL ? 1u : (pend_word & 0xFFu) + 1u;
+                    // whole waves: count of the lane's waiting entries, and (PACKL) bit 8: a deep entry of the lane may be waiting.
+                    // A small wave never picks its terms up again, so it keeps no count — only (PACKL) the NUMBER of the
+                    // lane's deep entries still waiting, in bits 8 up, taken down by whoever folds one (fold_pass)
+                    const unsigned pend_word = fq_pend[lane];
+                    const unsigned pend = SMALL ? 0u : (pend_word & 0xFFu) + 1u;
                     if constexpr (!SMALL) fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
                     fifo_full = !SMALL && pend >= 8u;
                     const bool deep_now = PACKL && depth > 16;
-                    fq_pend[lane] = pend | (pend_word & 0x100u) | (deep_now ? 0x100u : 0u);
+                    if constexpr (SMALL) {
+                        if constexpr (PACKL) fq_pend[lane] = pend_word + (deep_now ? 0x100u : 0u);
+                    } else {
+                        fq_pend[lane] = pend | (pend_word & 0x100u) | (deep_now ? 0x100u : 0u);
+                    }
                     if constexpr (PACKL) {
                         // Levels from 16 up sit in the lane's pooled stack and are read when the entry is folded, so the
                         // lane's next path must not write there before.  The lane has TWO pooled stacks and changes over
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         // one for every deep path (P(depth > 16) = 1.5 % of the paths: every fifth trip of a wave) ran the
                         // fold half empty that often: +4 % on the 512x512 unlimited-depth frame.
                         if (deep_now) {
-                            fifo_full = fifo_full || (pend_word & 0x100u) != 0u;
+                            fifo_full = fifo_full || (pend_word >> 8) != 0u;
                             stack.slot ^= 1;
                         }
                     }
