@@ -1,23 +1,17 @@
-// rtm_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) for the RaytracingMin hot path and
-// the device half of the C ABI in include/rtm.h.
+// rtm_kernels.hip — the device half of the C ABI in include/rtm.h: ONE translation unit that pulls in the hand-written
+// HIP kernels for gfx950 / CDNA4 and holds their host side.
 //
-// Path (reference file:line): Renderer::Render's pixel/sample loop src/Renderer.cpp:215-250,
-// png::PathTracing src/Renderer.cpp:57-117, SphereObject::Intersect src/SettingData.cpp:197-226,
-// vec3 math src/Ray.h:7-72, Material src/SettingData.h:8-17.
-//
-// Shape of the render kernel:
-//   * one 64-lane wavefront owns one 8x8 pixel tile, one lane per pixel; a lane walks its pixel's
-//     SS*SS*S samples in the reference's order (sx, sy, s) so the fp64 accumulation order is the
-//     reference's.
-//   * the per-sample recursion is flattened into one loop of ray casts with path regeneration: a
-//     lane whose path ended folds it, accumulates, and starts its next sample in the same
-//     iteration, so every live lane casts a ray on every iteration (no bounce-depth idling).
-//   * per-bounce hit records (the object index of every continued bounce) are staged in LDS,
-//     [depth][lane]; the radiance is folded back-to-front from them so the arithmetic order is
-//     the recursion's (L = colorKD * L_next + emission, src/Renderer.cpp:109).
-//   * the scene is brute-forced in index order (strict <, lowest index wins ties); sphere geometry
-//     is read with wave-uniform (scalar) loads, materials are gathered per lane.
-//   * no MFMA: there is no dense contraction on this path.  fp64 throughout, float islands kept.
+//   rtm_path.h           Math and Scene policies, SphereObject::Intersect / PlaneObject::Intersect, the nearest-hit search,
+//                        one PathTracing invocation, the back-to-front fold (src/Renderer.cpp:57-117, src/SettingData.cpp:197-249)
+//   rtm_render_kernel.h  render_tiles_kernel — the hot kernel (Renderer::Render's pixel/sample loop, src/Renderer.cpp:215-250)
+//                        — and split_finalize_kernel
+//   rtm_wavefront.h      the large-scene pipeline (BASELINE configs[4])
+//   rtm_fp32.h           the separately labelled single-precision row
+//   rtm_seam_kernels.h   per-ray / per-call seams, probes, self-checks, the fp64 peak kernel
+//   this file            scene lifetime (flattening, upload, deferred release), per-(device, stream) contexts and scratch,
+//                        variant selection, the sample-split plan, launches, the blocking conveniences, the test hooks
+// Shape of the render kernel: DESIGN.md §4.  No MFMA: there is no dense contraction on this path.  fp64 throughout,
+// float islands kept.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -42,1071 +36,12 @@
 #include "rtm_internal.h"
 #include "rtm_path.h"
 
-namespace rtm {
-
-struct RenderParams {
-    SceneView scene;
-    int W, H, S, SS;
-    int row_begin, row_end;
-    int band_count, band_index;  // interleaved 8-row bands (rtm_options); 1, 0 = every band
-    int tiles_x;
-    int mode, max_bounces;
-    unsigned total_samples;  // SS*SS*S per pixel
-    float rate;              // 1.0 / (1 + SS) as float, src/Renderer.cpp:227
-    double dSS, dS;          // divisors of src/Renderer.cpp:240
-    double inv_ss, inv_s;    // exact reciprocals when SS and S are powers of two, else 0
-    D3 cam_org, ax, by, cz;  // origin, camX*fovx, camY*fovy, camZ (src/Renderer.cpp:202-208)
-    uint64_t seed_mult;
-    double* __restrict__ out64;
-    float* __restrict__ out32;
-    uint8_t* __restrict__ out8;
-    unsigned long long* __restrict__ counters;  // casts, bounces, draws, overflow flag
-    // deep-path record pool (only when a path may run deeper than the LDS record stack)
-    unsigned char* __restrict__ pool;       // pool_slots x kPoolLevels records
-    unsigned* __restrict__ pool_next;       // bump allocator
-    unsigned pool_slots;
-    unsigned long long* __restrict__ stamps;  // STAMP builds: per block {nearest, shade, end, iterations}
-    // sample split (SPLIT kernels): `split` waves per tile; wave 0 traces samples [0, split_head), wave f >= 1
-    // samples [split_head + (f-1)*split_len, split_head + f*split_len)
-    // Tiles [0, split_first) are NOT split (one wave traces all their samples and stores the pixel itself): a
-    // long launch splits only its last tiles, whose short waves fill the SIMDs that the last whole tiles leave
-    // idle one after another.  n_tiles counts the split tiles; their blocks follow the whole tiles' in the grid.
-    unsigned n_tiles, split, split_head, split_len, split_first;
-    double* __restrict__ partial;  // [tile][3][64]: accumulator of wave 0 after its split_head samples
-    // per-sample terms of waves 1..: one block of split_len rows per (tile, small wave), a row = 64 terms in the order
-    // the wave FOLDED them ([3][64] doubles, whole lines from one store instruction) + 64 tags (owner lane, sample)
-    unsigned char* __restrict__ contrib;
-};
-constexpr size_t kTermRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned short);  // 1664 = 13 lines of 128 B
-
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-
-constexpr int kPoolLevels = 960;  // records per pool slot beyond the LDS levels
-
-// Per-lane stack of hit records: the first LDS_D levels live in LDS ([depth][lane]); a lane whose
-// path runs deeper takes, once, a slot of kPoolLevels records from a global pool.  Exhausting the
-// pool or the slot raises the overflow flag and the call fails with RTM_ERR_UNSUPPORTED.
-template <typename RecT, int LDS_D>
-struct RecordStack {
-    RecT* lds;  // this wave's [LDS_D][64]
-    int lane;
-    const RenderParams* P;
-    int slot = -1;
-    bool overflow = false;
-    __device__ __forceinline__ RecT* slot_ptr() {
-        if (slot < 0) {
-            const unsigned got = P->pool ? atomicAdd(P->pool_next, 1u) : 0xFFFFFFFFu;
-            if (got >= P->pool_slots) {
-                overflow = true;
-                return nullptr;
-            }
-            slot = (int)got;
-        }
-        return reinterpret_cast<RecT*>(P->pool) + (size_t)slot * kPoolLevels;
-    }
-    __device__ __forceinline__ void push(int d, int id) {
-        if (d < LDS_D) {
-            lds[d * 64 + lane] = (RecT)id;
-        } else if (d - LDS_D < kPoolLevels) {
-            if (RecT* p = slot_ptr()) p[d - LDS_D] = (RecT)id;
-        } else {
-            overflow = true;
-        }
-    }
-    __device__ __forceinline__ int pop(int d) {
-        if (d < LDS_D) return (int)lds[d * 64 + lane];
-        if (slot < 0 || d - LDS_D >= kPoolLevels) return 0;  // only after an overflow: image is discarded
-        return (int)(reinterpret_cast<const RecT*>(P->pool) + (size_t)slot * kPoolLevels)[d - LDS_D];
-    }
-    static constexpr int kCapacity = LDS_D + kPoolLevels;
-};
-
-// LDS copy of the scene tables: n geometry rows (4 doubles) + n+1 material rows (8 doubles, the last
-// one is the identity row) + n normal-length rows (3 doubles: |hit - centre| as Magnitude returns it, its refined
-// reciprocal, and the float r*r in the low word of the third)
-__host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 7 + ((size_t)n + 1) * 8) * sizeof(double); }
-
-// src/Renderer.cpp:227-232; sx, sy in 1..SS
-__device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, int sx, int sy) {
-    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
-    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
-    return normalize((P.ax * px + P.by * py) + P.cz);
-}
-
-// The same, with the nine camera-basis doubles read from an LDS block (cam[0..8] = ax, by, cz).  The
-// block is read once per sub-pixel; keeping those doubles in registers across the render loop made
-// hipcc spill them to scratch per lane (200 MB of stray HBM writes per 1080p frame).
-__device__ __forceinline__ D3 primary_dir_lds(const RenderParams& P, const double* cam, int x, int y, int sx,
-                                              int sy) {
-    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
-    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
-    const D3 ax = d3(cam[0], cam[1], cam[2]), by = d3(cam[3], cam[4], cam[5]), cz = d3(cam[6], cam[7], cam[8]);
-    return normalize((ax * px + by * py) + cz);
-}
-
-__device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsigned v) {
-    unsigned long long s = v;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
-}
-
-// src/Renderer.cpp:246-254: image[] += acc; optional float3 / 8-bit views of the same pixel
-// Image row of row `sub` (0..7) of this call's band `local_band`: the call renders bands
-// band_index, band_index + band_count, ... of [row_begin, row_end) and stores them back to back.
-__device__ __forceinline__ int band_row(const RenderParams& P, int local_band, int sub) {
-    return P.row_begin + (local_band * P.band_count + P.band_index) * 8 + sub;
-}
-
-__device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, int x, int y, D3 acc) {
-    if (!valid) return;
-    const int rel = y - P.row_begin;
-    const int out_row = (P.band_count > 1) ? ((rel >> 3) / P.band_count) * 8 + (rel & 7) : rel;
-    const size_t o = ((size_t)out_row * P.W + x) * 3;
-    const double r = 0.0 + acc.x, g = 0.0 + acc.y, b = 0.0 + acc.z;  // :246-248
-    if (P.out64) {
-        P.out64[o] = r;
-        P.out64[o + 1] = g;
-        P.out64[o + 2] = b;
-    }
-    if (P.out32) {
-        P.out32[o] = (float)r;
-        P.out32[o + 1] = (float)g;
-        P.out32[o + 2] = (float)b;
-    }
-    if (P.out8) {  // :253: (unsigned char)255 * std::min(v, 1.0), truncation
-        const double q[3] = {r, g, b};
-        for (int c = 0; c < 3; ++c) {
-            const double v = 255 * ((1.0 < q[c]) ? 1.0 : q[c]);
-            P.out8[o + c] = (v >= 0.0 && v < 256.0) ? (uint8_t)v : (uint8_t)0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The render kernel.
-//   M       Math policy (rtm_path.h)
-//   LDS_TAB scene tables (centres + materials) copied to LDS for the per-lane look-ups
-//   UNROLL  spheres whose geometry is fetched together (wave-uniform loads)
-//   RecT    hit-record type (u8 when n_spheres <= 256), LDS_D: record depth staged in LDS per lane
-// Dynamic LDS layout (16-byte aligned base): [geom n*4 doubles][mat (n+1)*8][norm n*2] (LDS_TAB), [camera 10]
-// [sincos constants 16][accumulator + primary direction 6 x 64] (PARK), then the record stack
-// [LDS_D][64] or the fold queue (DEFER).
-//   PARK    the pixel accumulator and the cached primary direction live in LDS ([component][lane]),
-//           not in VGPRs: they are touched once per sample, and the 12 registers they would pin
-//           are what the unrolled sphere chunk needs to stay under 128 VGPRs without scratch spills
-//   STAMP   diagnostic build: s_memtime around the three segments of an iteration (never timed itself)
-//   PACK8   max_bounces <= 8 and n < 256: hit records packed in a 64-bit register, no LDS stack
-//   SPLIT   P.split waves per tile, each tracing a contiguous range of the pixel's samples.  Wave 0
-//           accumulates as usual and leaves its accumulator in P.partial; the others store every
-//           sample's term (src/Renderer.cpp:240-242, after the clamp) to P.contrib, and
-//           split_finalize_kernel adds them IN THE REFERENCE'S ORDER, so the image does not change by
-//           a bit.  Used when a strip has too few tiles to keep every SIMD busy to the end (few rows
-//           per GPU, small images): the launch's tail is then the spread of per-tile cost.
-//   DEFER   (with PACK8 + PARK) path ends are queued and folded 64 at a time.  The fold, the /SS/SS/S and
-//           the clamp of a finished path are a pure function of its hit ids, but only ~22 % of the
-//           lanes finish a path in a given iteration, so doing that work on the spot runs ~100
-//           instructions with a fifth of the lanes (13 % of the frame, measured).  Instead the ending
-//           lanes append (records, terminal id) to a wave-shared ring in LDS and start their next
-//           sample at once; whenever 64 entries are waiting, all 64 lanes fold one entry each and leave
-//           the term in LDS, and every owner then adds its terms to its accumulator in the order its
-//           paths ended (a per-lane FIFO of ring positions keeps that order) — the accumulation order
-//           of src/Renderer.cpp:241-242 is untouched.
-//   PACKL   (with DEFER) packed records for paths of ANY depth (max_bounces < 0 or > 8): level d in byte
-//           d & 7 of word d >> 3 — word 0 in a register, word 1 in LDS per lane, levels from 16 up (about
-//           kd^16 of the paths) in the pooled global stack.  A queue entry carries both words and the pool
-//           slot; a lane that queues a path deeper than 16 forces a pass, so its slot is free again
-//           before its next path can reach level 16.
-//   REUSE   (with DEFER + PACK8; variant 15, a SEPARATELY LABELLED row, never the default) the S samples of a
-//           sub-pixel share one primary ray (no jitter, src/Renderer.cpp:224-232), so its nearest hit is computed
-//           once per sub-pixel and reused: a lane whose path ended restarts at "primary hit known" in the SAME
-//           trip and joins the shading block with the lanes that bounced.  Every trip is then one nearest-hit
-//           search and one bounce for every lane (no idle lanes in either block) and a sample costs C - 1 trips
-//           instead of C.  Same image, same counters (a reused primary hit still counts as the cast the reference
-//           performs); different work per sample than the reference, hence the label.
-constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
-constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
-constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
-// (SPLIT: a small wave's ring entries carry a 2-byte tag (owner lane, sample).  The tags live in the per-lane FIFO array,
-// which a small wave does not use: 256 of its 512 bytes.  A separate array put the any-depth kernel at 10 328 bytes of LDS per
-// wave — 15 instead of 16 waves per CU, 5 % on every unlimited-depth frame, profiles/r3/ab_r2_vs_r3.txt.)
-constexpr size_t kFoldTagBytes = 0;
-
-//   PLANES  (with LDS_TAB) the scene holds png::PlaneObject entries: SceneLdsObjects / object_chunk / MathSpecZ
-//           (rtm_path.h) — a plane's test in its index slot of the chunk, its normal from the LDS table
-template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
-          bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false,
-          bool REUSE = false, bool PLANES = false>
-__global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
-    static_assert(!PLANES || (LDS_TAB && !REUSE), "plane scenes ride on the LDS tables");
-    static_assert(!SPLIT || DEFER, "the sample split's small waves store their terms from the fold queue");
-    static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
-    static_assert(!REUSE || (DEFER && PACK8 && !SPLIT), "primary-hit reuse rides on the deferred fold with packed records");
-    static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x;
-    double* lgeom = reinterpret_cast<double*>(lds_raw);
-    double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
-    double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
-    double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
-    double* trig = cam + 10;                 // 9 camera doubles + pad
-    double* park = trig + kTrigConstCount;   // 16 sincos constants
-    RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
-    // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
-    uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
-    double* fq_out = reinterpret_cast<double*>(fq_in + kFoldRing);
-    unsigned long long* fq_fifo = reinterpret_cast<unsigned long long*>(fq_out + 3 * 64);
-    unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
-    unsigned long long* fq_in1 = reinterpret_cast<unsigned long long*>(fq_pend + 64);  // PACKL: word 1 of the entries
-    unsigned long long* rec_w1 = fq_in1 + kFoldRing;                                   // PACKL: word 1 of the lanes
-    // SPLIT, small waves only: tag of every ring entry, in the FIFO array they have no other use for
-    unsigned short* fq_tag = reinterpret_cast<unsigned short*>(fq_fifo);
-    static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
-    if constexpr (DEFER) fq_pend[lane] = 0u;
-    if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
-    if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
-    if (lane < 9) {
-        const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
-        double pick = v9[0];
-#pragma unroll
-        for (int k = 1; k < 9; ++k) pick = (lane == k) ? v9[k] : pick;
-        cam[lane] = pick;
-    }
-    __syncthreads();
-    if constexpr (LDS_TAB) {
-        const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
-        for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
-        for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
-        for (int i = lane; i < P.scene.n; i += 64) {
-            if (PLANES && gsrc[i * 4 + 3] < 0.0) {  // a plane's row: its normal (SceneLdsObjects::plane_normal)
-                lnrm[i * 3] = P.scene.plane[(size_t)i * 16 + 3];
-                lnrm[i * 3 + 1] = P.scene.plane[(size_t)i * 16 + 4];
-                lnrm[i * 3 + 2] = P.scene.plane[(size_t)i * 16 + 5];
-                continue;
-            }
-            const double ms = (double)__builtin_sqrtf((float)gsrc[i * 4 + 3]);
-            lnrm[i * 3] = ms;
-            lnrm[i * 3 + 1] = refined_rcp_or_nan(ms);
-            reinterpret_cast<float*>(lnrm + i * 3 + 2)[0] = (float)gsrc[i * 4 + 3];  // r*r as the float it is
-        }
-        __syncthreads();  // one wave per block: orders the LDS writes before the reads
-    }
-    using Scene = typename std::conditional<PLANES, SceneLdsObjects,
-                                            typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type>::type;
-    Scene sc;
-    sc.v = P.scene;
-    if constexpr (LDS_TAB) {
-        sc.lgeom = lgeom;
-        sc.lmat = lmat;
-        sc.lnrm = lnrm;
-    }
-
-    // Pixel coordinates are recomputed where they are needed (sub-pixel change, final store) from an
-    // opaque copy of the lane id, so that nothing derived from them stays live across the render loop.
-    auto pixel_xy = [&](int& px, int& py) {
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        const unsigned tile = (SPLIT && blockIdx.x >= P.split_first)
-                                  ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles : blockIdx.x;
-        const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-        px = tx * 8 + (l & 7);
-        py = band_row(P, ty, l >> 3);
-    };
-    int x, y;
-    pixel_xy(x, y);
-    const bool valid = (x < P.W) && (y < P.row_end);
-    const uint32_t pixel = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;  // GLOBAL pixel index
-
-    PathCounters pc = {0, 0, 0};
-    RecordStack<RecT, LDS_D> stack{rec, lane, &P};
-    if constexpr (PACKL) {
-        if (P.pool) stack.slot = (int)((blockIdx.x * 64u + (unsigned)lane) * 2u);  // two pooled stacks per lane, no allocator
-    }
-    D3 acc = d3(0, 0, 0);
-
-    // this wave's samples [n_first, n_end) of the pixel (wave-uniform)
-    const bool whole = !SPLIT || blockIdx.x < P.split_first;  // this wave traces all samples of its tile
-    // Which wave of a split tile this is, recomputed from an OPAQUE copy of the block index wherever it is needed (a
-    // small wave's fold passes, the head wave's final store): kept live across the render loop, these scalars pushed
-    // hipcc over its SGPR budget and it spilled loop-carried scalars to VGPR lanes (27 v_readlane / v_writelane more in
-    // the kernel: +1 % on the headline frame, profiles/r3/ab_r2_vs_r3.txt).
-    auto split_wave = [&](unsigned& f, unsigned& tile) {
-        unsigned b = blockIdx.x;
-        asm volatile("" : "+s"(b));
-        f = (b - P.split_first) / P.n_tiles;
-        tile = (b - P.split_first) % P.n_tiles;  // index into partial / contrib
-    };
-    unsigned n_first = 0u, n_end = P.total_samples;
-    if (!whole) {
-        unsigned f, tile;
-        split_wave(f, tile);
-        n_first = f != 0u ? P.split_head + (f - 1u) * P.split_len : 0u;
-        n_end = f != 0u ? n_first + P.split_len : P.split_head;
-    }
-    // a SMALL wave of the sample split (wave-uniform; its first sample is never 0: wave 0 keeps at least one share):
-    // it accumulates nothing — every term goes to P.contrib in the order the wave folds them, 64 to a row, and
-    // split_finalize_kernel puts each pixel's terms back in sample order
-    // The render loop is compiled TWICE into a SPLIT kernel (`trace` below, generic over a compile-time tag) and a wave
-    // picks its copy once: a whole or head wave runs exactly the loop of the unsplit kernel, a small wave a loop without
-    // the per-lane FIFO.  One copy with wave-uniform "am I small" branches cost every whole wave of a split launch 1 %
-    // (profiles/r3/ab_r2_vs_r3.txt: 181.1 against round 2's 179.3 ms with 64 split tiles).
-    unsigned terms_out = 0;  // terms this small wave has stored (wave-uniform)
-    unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
-    int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
-    const int sub_first = (int)(n_first / (unsigned)P.S);
-    D3 pdir = primary_dir_lds(P, cam, x, y, sub_first / P.SS + 1, sub_first % P.SS + 1);
-    D3 org = P.cam_org, dir = pdir;
-    int depth = 0;
-    const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
-    RngStream rng = rng_open(pkey, n_first);
-    if constexpr (PARK) {
-        park[0 * 64 + lane] = 0.0;
-        park[1 * 64 + lane] = 0.0;
-        park[2 * 64 + lane] = 0.0;
-        park[3 * 64 + lane] = pdir.x;
-        park[4 * 64 + lane] = pdir.y;
-        park[5 * 64 + lane] = pdir.z;
-    }
-
-    unsigned long long recq = packed8_empty(P.scene.n);  // PACK8 records, most recent bounce in the low byte
-    auto push = [&](int d, int id) {
-        if constexpr (PACK8) {
-            recq = (recq << 8) | (unsigned long long)(unsigned)id;
-        } else if constexpr (PACKL) {
-            // the byte still holds the identity index: xor turns it into id
-            const unsigned long long flip = (unsigned long long)((unsigned)id ^ (unsigned)P.scene.n) << (8 * (d & 7));
-            if (d < 8)
-                recq ^= flip;
-            else if (d < 16)
-                rec_w1[lane] ^= flip;
-            else
-                stack.push(d - 16, id);  // LDS_D == 0: straight to the pooled stack
-        } else {
-            stack.push(d, id);
-        }
-    };
-    auto pop = [&](int d) -> int { return stack.pop(d); };
-    const bool pow2 = P.inv_s != 0.0;  // wave-uniform
-
-    // DEFER: ring indices (wave-uniform) and one pass of the queue
-    unsigned fq_head = 0, fq_tail = 0, fq_count = 0;
-    auto fold_pass = [&](auto small_tag) {
-        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
-        const unsigned m = fq_count < 64u ? fq_count : 64u;
-        if ((unsigned)lane < m) {
-            const unsigned at = (fq_head + (unsigned)lane) & (kFoldRing - 1);
-            const uint4 e = fq_in[at];
-            const unsigned long long w0 = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
-            D3 L;
-            if constexpr (PACKL)
-                L = path_fold_packed16(sc, (int)(e.z & 0xFFu), (int)(e.z >> 8), w0, fq_in1[at],
-                                       P.pool + (size_t)e.w * kPoolLevels);
-            else
-                L = path_fold_packed8_all(sc, (int)e.z, w0);
-            const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;  // :240
-            const D3 add = clamp01_d3(cal);
-            if constexpr (SMALL) {
-                // Whole lines from one instruction: the 64 folding lanes write their terms back to back (three 512-byte
-                // rows) with the entry's tag behind them.  Round 2 let every OWNER store its term into a [sample][lane]
-                // cell: 32-byte stores scattered over the tile's buffer, each completed to the memory's 64-byte granule by
-                // a read (PMC: 4.5 GB fetched + 1.6 GB written per headline launch for 1.2 GB of terms).
-                unsigned sf, stile;
-                split_wave(sf, stile);
-                unsigned char* term_rows = P.contrib + ((size_t)stile * (P.split - 1u) + (sf - 1u)) * P.split_len * kTermRowBytes;
-                const unsigned pos = terms_out + (unsigned)lane;
-                unsigned char* row = term_rows + (size_t)(pos >> 6) * kTermRowBytes;
-                double* v = reinterpret_cast<double*>(row) + (pos & 63u);
-                // NON-TEMPORAL stores: a plain store of a whole 512-byte row still made L2 fetch the lines it was about to
-                // overwrite (PMC, profiles/r3/term_store_modes.txt: 1.25 GB fetched in the render kernel against 0.48 with
-                // `nt`; 16-byte-per-lane stores through LDS changed nothing)
-                __builtin_nontemporal_store(add.x, v);
-                __builtin_nontemporal_store(add.y, v + 64);
-                __builtin_nontemporal_store(add.z, v + 128);
-                const unsigned tag = fq_tag[at];
-                __builtin_nontemporal_store((unsigned short)tag, reinterpret_cast<unsigned short*>(row + 3 * 64 * sizeof(double)) + (pos & 63u));
-                if constexpr (PACKL) {
-                    // this entry's levels from 16 up have just been read from its owner's pooled stack: one deep entry fewer
-                    // of that lane is waiting (two folding lanes may serve the same owner in one pass: an LDS atomic)
-                    if ((e.z >> 8) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
-                }
-            } else {
-                fq_out[0 * 64 + lane] = add.x;
-                fq_out[1 * 64 + lane] = add.y;
-                fq_out[2 * 64 + lane] = add.z;
-            }
-        }
-        if constexpr (SMALL) {
-            terms_out += m;
-        } else {
-            // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
-            for (;;) {
-                const unsigned pend = fq_pend[lane] & 0xFFu;  // (PACKL: bit 8 = "a deep entry of this lane may be waiting")
-                const unsigned oldest = (unsigned)(fq_fifo[lane] >> (8u * ((pend ? pend : 1u) - 1u))) & 0xFFu;
-                const unsigned rel = (oldest - fq_head) & (kFoldRing - 1);
-                const bool mine = pend != 0u && rel < m;
-                if (__builtin_amdgcn_ballot_w64(mine) == 0) break;
-                if (mine) {
-                    park[0 * 64 + lane] += fq_out[0 * 64 + rel];
-                    park[1 * 64 + lane] += fq_out[1 * 64 + rel];
-                    park[2 * 64 + lane] += fq_out[2 * 64 + rel];
-                    // (the last of the lane's entries: the deep flag goes too; otherwise it stays)
-                    fq_pend[lane] = pend == 1u ? 0u : (fq_pend[lane] - 1u);
-                }
-            }
-        }
-        fq_head = (fq_head + m) & (kFoldRing - 1);
-        fq_count -= m;
-        // a small wave's queue has run empty: none of its lanes has an entry waiting, deep or not
-        (void)small_tag;
-    };
-
-    (void)fold_pass;
-    // wave-level counters of the DEFER loop (scalar registers): every live lane casts once per trip
-    unsigned w_casts = 0, w_bounces = 0, w_draws = 0;
-    if constexpr (DEFER && REUSE) {
-        // ---- primary-hit reuse (see REUSE above) ----
-        // the primary hit of the lane's current sub-pixel: recomputed when the sub-pixel changes (once per S samples)
-        double pdis;
-        int pid = nearest_hit<M, UNROLL>(sc, P.cam_org, pdir, pdis);
-        int id = pid;       // the hit the lane is about to classify ...
-        double dis = pdis;  // ... for its ray (org, dir) at `depth`; every lane starts at its first sample's primary hit
-        bool have_fresh_rays = false;
-        for (;;) {
-            const unsigned long long m_live0 = __builtin_amdgcn_ballot_w64(n < n_end);
-            if (m_live0 == 0ull) break;
-            if (have_fresh_rays) id = nearest_hit<M, UNROLL>(sc, org, dir, dis);  // wave-uniform: one search per lane and trip
-            // ---- classify until every live lane holds a hit whose path continues (src/Renderer.cpp:74-78, :112, :116) ----
-            bool settled = !(n < n_end);  // a lane past its range: nothing to classify; it shades a dummy below
-            for (;;) {
-                const bool pending = !settled;
-                const unsigned long long m_pend = __builtin_amdgcn_ballot_w64(pending);
-                if (m_pend == 0ull) break;
-                bool ends = false, drew = false, fifo_full = false;
-                if (pending) {
-                    const bool capped = P.max_bounces >= 0 && depth >= P.max_bounces;
-                    drew = id >= 0 && !capped;
-                    bool rr_pass = false;
-                    if (drew) rr_pass = rng_next_m(rng) <= sc.kd24(id);  // :78
-                    ends = !rr_pass;
-                    settled = rr_pass;
-                    if (ends) {
-                        // queue this path end: ring position = tail + rank among the lanes ending now
-                        const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
-                        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
-                        const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                        const unsigned term_id = (unsigned)(id < 0 ? P.scene.n : id);
-                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
-                        const unsigned pend = fq_pend[lane] + 1u;
-                        fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
-                        fq_pend[lane] = pend;
-                        fifo_full = pend >= 8u;
-                        // next sample of this pixel: its primary ray and — new — its primary hit
-                        ++n;
-                        if (--left_in_sub == 0) {
-                            left_in_sub = P.S;
-                            if (n < n_end) {
-                                const int sub = (int)(n / (unsigned)P.S);
-                                int px, py;
-                                pixel_xy(px, py);
-                                pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
-                                park[3 * 64 + lane] = pdir.x;
-                                park[4 * 64 + lane] = pdir.y;
-                                park[5 * 64 + lane] = pdir.z;
-                                pid = nearest_hit<M, UNROLL>(sc, P.cam_org, pdir, pdis);  // once per S samples
-                            }
-                        }
-                        org = P.cam_org;
-                        dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
-                        depth = 0;
-                        recq = packed8_empty(P.scene.n);
-                        rng = rng_open(pkey, n);
-                        id = pid;
-                        dis = pdis;
-                        settled = !(n < n_end);  // out of samples: done (shades a dummy below)
-                    }
-                }
-                // counters: every classified hit is one PathTracing invocation of the reference
-                w_casts += (unsigned)__builtin_popcountll(m_pend);
-                w_draws += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(drew));
-                const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ends));
-                if (added != 0u) {
-                    fq_tail = (fq_tail + added) & (kFoldRing - 1);
-                    fq_count += added;
-                    const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;
-                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(std::false_type{});
-                }
-            }
-            // ---- bounce: every lane holds a hit that passed the roulette (lanes out of samples: a dummy) ----
-            const bool live = n < n_end;
-            const unsigned n_live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
-            if (n_live == 0u) break;
-            const int sid = id < 0 ? 0 : id;  // dummies may hold a miss; the scene has at least one sphere here
-            ShadeOut o;
-            {
-                MathSpec m;
-                m.trig_lds = trig;
-                path_bounce_core(m, sc, sid, dis, P.mode, org, dir, rng, o);
-                if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
-                    MathRefI r;
-                    r.trig_lds = trig;
-                    path_bounce_core(r, sc, sid, dis, P.mode, org, dir, rng, o);
-                }
-            }
-            w_draws += 2u * n_live;
-            w_bounces += n_live;
-            push(depth, sid);
-            depth++;
-            org = o.org;
-            dir = o.dir;
-            rng.ctr = o.ctr;
-            have_fresh_rays = true;
-        }
-        while (fq_count > 0u) fold_pass(std::false_type{});
-    }
-    if constexpr (DEFER && !REUSE) {
-      auto trace = [&](auto small_tag) {
-        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
-        // Wave-uniform loop: fold_pass needs all 64 lanes whatever their own state, so a lane that has finished
-        // its samples cannot leave.  It does not idle either: it keeps tracing (samples beyond its range, results
-        // discarded — `live` gates the queue, the counters and nothing else), which costs nothing — the lanes are
-        // there anyway — and keeps the whole body free of a per-lane "am I still in range" region, i.e. of the
-        // exec-mask bookkeeping and register copies hipcc generates around one (-14 VALU per trip).
-        for (;;) {
-            // lane masks as scalars (SGPR pairs straight from the compares): every count below is a popcount
-            const unsigned long long m_live = __builtin_amdgcn_ballot_w64(n < n_end);
-            if (m_live == 0ull) break;
-            const bool live = n < n_end;
-            bool fifo_full = false;
-            D3 term;
-            int hit_id;
-            const int depth_before = depth;
-            PathCounters unused = {0, 0, 0};
-            bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
-                                             trig, &hit_id);
-            if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
-            // counters (src/Renderer.cpp has none; rtm_stats): one cast per live lane, one draw for the RR test of a
-            // hit below the depth cap, two more and a bounce when the path continues
-            const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_live;
-            unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_live;
-            if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
-            const unsigned n_cont = (unsigned)__builtin_popcountll(m_cont);
-            w_casts += (unsigned)__builtin_popcountll(m_live);
-            w_draws += (unsigned)__builtin_popcountll(m_drew) + 2u * n_cont;
-            w_bounces += n_cont;
-            if (!cont) {
-                if (live) {
-                    // queue this path end: ring position = tail + rank among the lanes ending now
-                    const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
-                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
-                    const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                    const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
-                    if constexpr (PACKL) {
-                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
-                                           (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
-                        fq_in1[pos] = rec_w1[lane];
-                    } else {
-                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
-                    }
-                    if constexpr (SPLIT) {
-                        if constexpr (SMALL) fq_tag[pos] = (unsigned short)((unsigned)lane | ((n - n_first) << 6));
-                    }
-                    // whole waves: count of the lane's waiting entries, and (PACKL) bit 8: a deep entry of the lane may be waiting.
-                    // A small wave never picks its terms up again, so it keeps no count — only (PACKL) the NUMBER of the
-                    // lane's deep entries still waiting, in bits 8 up, taken down by whoever folds one (fold_pass)
-                    const unsigned pend_word = fq_pend[lane];
-                    const unsigned pend = SMALL ? 0u : (pend_word & 0xFFu) + 1u;
-                    if constexpr (!SMALL) fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
-                    fifo_full = !SMALL && pend >= 8u;
-                    const bool deep_now = PACKL && depth > 16;
-                    if constexpr (SMALL) {
-                        if constexpr (PACKL) fq_pend[lane] = pend_word + (deep_now ? 0x100u : 0u);
-                    } else {
-                        fq_pend[lane] = pend | (pend_word & 0x100u) | (deep_now ? 0x100u : 0u);
-                    }
-                    if constexpr (PACKL) {
-                        // Levels from 16 up sit in the lane's pooled stack and are read when the entry is folded, so the
-                        // lane's next path must not write there before.  The lane has TWO pooled stacks and changes over
-                        // whenever it queues such a path; only if the other one may still be waiting in the queue (a second
-                        // deep path before the lane's entries have all been folded: rare squared) is a pass forced.  Forcing
-                        // one for every deep path (P(depth > 16) = 1.5 % of the paths: every fifth trip of a wave) ran the
-                        // fold half empty that often: +4 % on the 512x512 unlimited-depth frame.
-                        if (deep_now) {
-                            fifo_full = fifo_full || (pend_word >> 8) != 0u;
-                            stack.slot ^= 1;
-                        }
-                    }
-                }
-                if constexpr (PACKL) {
-                    if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
-                }
-                // next sample of this pixel (src/Renderer.cpp:236-239); a lane past its range stays at n_end, so that
-                // "n - pending" remains the sample index of its queued path ends (fold_pass, SPLIT)
-                n += live ? 1u : 0u;
-                if (--left_in_sub == 0) {
-                    left_in_sub = P.S;
-                    const int sub = (int)(n / (unsigned)P.S);
-                    int px, py;
-                    pixel_xy(px, py);
-                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
-                    park[3 * 64 + lane] = pdir.x;
-                    park[4 * 64 + lane] = pdir.y;
-                    park[5 * 64 + lane] = pdir.z;
-                }
-                org = P.cam_org;
-                dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
-                depth = 0;
-                recq = packed8_empty(P.scene.n);
-                rng = rng_open(pkey, n);
-            }
-            const unsigned added = (unsigned)__builtin_popcountll(m_live & ~m_cont);
-            if (added != 0u) {
-                fq_tail = (fq_tail + added) & (kFoldRing - 1);
-                fq_count += added;
-                const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;  // a lane's FIFO holds 8 positions
-                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(small_tag);
-            }
-        }
-        while (fq_count > 0u) fold_pass(small_tag);
-      };
-      if constexpr (SPLIT) {
-          if (n_first != 0u) trace(std::true_type{});  // (a small wave's first sample is never 0: wave 0 keeps at least one share)
-          else trace(std::false_type{});
-      } else {
-          trace(std::false_type{});
-      }
-    }
-    unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
-    while (!DEFER && n < n_end) {
-        D3 term;
-        bool cont;
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-        if constexpr (STAMP) {
-            ts0 = stamp_now();
-            double dis;
-            const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
-            ts1 = stamp_now();
-            cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
-            ts2 = stamp_now();
-        } else {
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
-        }
-        if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
-            cont = false;
-            term = d3(0, 0, 0);
-            depth = 0;
-        }
-        if (!cont) {
-            // all ending lanes within the LDS levels (always, when max_bounces < 16): blocked fold
-            const bool deep = depth > LDS_D;
-            D3 L;
-            if constexpr (PACK8)
-                L = path_fold_packed8(sc, term, depth, recq);
-            else
-                L = (__builtin_amdgcn_ballot_w64(deep) == 0)
-                        ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
-                        : path_fold(sc, term, depth, pop);
-            // :240 cal / SS / SS / S.  x/2^k and x*2^-k are the same correctly rounded value, so
-            // power-of-two divisors are applied as multiplications.
-            const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
-            const D3 add = clamp01_d3(cal);
-            if constexpr (PARK) {  // :241-242 on the LDS-resident accumulator
-                park[0 * 64 + lane] += add.x;
-                park[1 * 64 + lane] += add.y;
-                park[2 * 64 + lane] += add.z;
-            } else {
-                acc = acc + add;
-            }
-            ++n;
-            if (--left_in_sub == 0) {
-                left_in_sub = P.S;
-                if (n < n_end) {
-                    const int sub = (int)(n / (unsigned)P.S);
-                    int px, py;
-                    pixel_xy(px, py);
-                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
-                    if constexpr (PARK) {
-                        park[3 * 64 + lane] = pdir.x;
-                        park[4 * 64 + lane] = pdir.y;
-                        park[5 * 64 + lane] = pdir.z;
-                    }
-                }
-            }
-            org = P.cam_org;
-            if constexpr (PARK)
-                dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
-            else
-                dir = pdir;
-            depth = 0;
-            if constexpr (PACK8) recq = packed8_empty(P.scene.n);
-            rng = rng_open(pkey, n);
-        }
-        if constexpr (STAMP) {
-            const unsigned long long ts3 = stamp_now();
-            st_near += ts1 - ts0;
-            st_shade += ts2 - ts1;
-            st_end += ts3 - ts2;
-            st_iters += 1;
-        }
-    }
-    if constexpr (STAMP) {
-        if (lane == 0 && P.stamps) {
-            P.stamps[blockIdx.x * 4 + 0] = st_near;
-            P.stamps[blockIdx.x * 4 + 1] = st_shade;
-            P.stamps[blockIdx.x * 4 + 2] = st_end;
-            P.stamps[blockIdx.x * 4 + 3] = st_iters;
-        }
-    }
-
-    if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
-    if (whole) {
-        int px, py;
-        pixel_xy(px, py);
-        store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
-    } else if (n_first == 0u) {  // the head wave of a split tile
-        unsigned hf, split_tile;
-        split_wave(hf, split_tile);
-        double* dst = P.partial + (size_t)split_tile * 192 + lane;
-        dst[0] = acc.x;
-        dst[64] = acc.y;
-        dst[128] = acc.z;
-    }
-    if (P.counters) {
-        if constexpr (DEFER) {
-            if (lane == 0) {
-                atomicAdd(P.counters + 0, (unsigned long long)w_casts);
-                atomicAdd(P.counters + 1, (unsigned long long)w_bounces);
-                atomicAdd(P.counters + 2, (unsigned long long)w_draws);
-            }
-        } else {
-            wave_add_counter(P.counters + 0, pc.casts);
-            wave_add_counter(P.counters + 1, pc.bounces);
-            wave_add_counter(P.counters + 2, pc.draws);
-        }
-        if (stack.overflow) atomicOr(P.counters + 3, 1ull);
-    }
-}
-
-// Second half of a SPLIT render: image[pixel] = (((partial + term[split_head]) + term[split_head+1]) + ...), the
-// accumulation order of src/Renderer.cpp:241-242.  One workgroup of four waves per split tile.  The small waves left
-// their terms in FOLD order (render_tiles_kernel: rows of 64 terms + tags); for one small wave at a time the block
-// scatters its rows into LDS by (sample, owner lane) — the tag — and waves 0..2 then add, each for ONE colour channel
-// (the three sums are independent), their pixel's terms in sample order.  LDS: split_len x 64 x 3 doubles (96 KB at
-// the 64 samples a small wave traces at most).
-__global__ __launch_bounds__(256) void split_finalize_kernel(const RenderParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double* slot = reinterpret_cast<double*>(lds_raw);  // [channel][sample][lane]
-    const int tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
-    const unsigned tile = P.split_first + blockIdx.x;  // blockIdx.x: index among the split tiles
-    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-    const int px = tx * 8 + (lane & 7), py = band_row(P, ty, lane >> 3);
-    const bool valid = (px < P.W) && (py < P.row_end);
-    // terms a small wave of this tile has stored: one per valid pixel and sample of its range
-    const unsigned n_valid = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));
-    const unsigned n_terms = n_valid * P.split_len;
-    const unsigned plane_sz = P.split_len * 64u;  // doubles per channel
-    double acc = chan < 3 ? P.partial[(size_t)blockIdx.x * 192 + chan * 64 + lane] : 0.0;
-    for (unsigned f = 1; f < P.split; ++f) {
-        const unsigned char* rows = P.contrib + ((size_t)blockIdx.x * (P.split - 1u) + (f - 1u)) * P.split_len * kTermRowBytes;
-        for (unsigned e = (unsigned)tid; e < n_terms; e += 256u) {
-            const unsigned char* row = rows + (size_t)(e >> 6) * kTermRowBytes;
-            const double* v = reinterpret_cast<const double*>(row) + (e & 63u);
-            const unsigned tag = reinterpret_cast<const unsigned short*>(row + 3 * 64 * sizeof(double))[e & 63u];
-            const unsigned at = (tag >> 6) * 64u + (tag & 63u);  // [sample][owner lane]
-            slot[at] = v[0];
-            slot[plane_sz + at] = v[64];
-            slot[2 * plane_sz + at] = v[128];
-        }
-        __syncthreads();
-        if (chan < 3) {
-            const double* mine = slot + (size_t)chan * plane_sz + lane;
-            for (unsigned m = 0; m < P.split_len; ++m) acc = acc + mine[m * 64u];  // (an invalid pixel adds stale LDS: never stored)
-        }
-        __syncthreads();
-    }
-    if (chan < 3) slot[chan * 64 + lane] = acc;
-    __syncthreads();
-    if (chan == 0) store_pixel(P, valid, px, py, d3(slot[lane], slot[64 + lane], slot[128 + lane]));
-}
-
-}  // namespace rtm
+#include "rtm_render_kernel.h"
 #include "rtm_wavefront.h"
 #include "rtm_fp32.h"
+#include "rtm_seam_kernels.h"
+
 namespace rtm {
-
-// ------------------------------------------------------------------------------------------------
-// Per-ray seam: png::PathTracing for a batch of rays (one lane per ray).
-struct RayBatchParams {
-    SceneView scene;
-    int mode, max_bounces;
-    uint64_t seed_mult;
-    const double* __restrict__ org;
-    const double* __restrict__ dir;
-    size_t n_rays;
-    double* __restrict__ out;
-    uint32_t* __restrict__ out_draws;
-    uint32_t* __restrict__ out_casts;
-    uint32_t* __restrict__ scratch;  // [depth][ray] hit records, RAY_MAX_DEPTH deep
-    unsigned long long* __restrict__ counters;
-    // debugging aid (RTM_DEBUG_SEAM_KEY="pixel,sample"): every ray draws from that stream instead of (i, 0),
-    // so one sample of a rendered frame can be replayed through the per-ray seam
-    int key_override;
-    uint32_t key_pixel, key_sample;
-    double* __restrict__ trace;  // debugging aid: (org, dir) of ray 0 at every cast, 6 doubles each
-    int trace_cap;
-};
-constexpr int RAY_MAX_DEPTH = 4096;
-
-__global__ __launch_bounds__(64) void path_trace_rays_kernel(const RayBatchParams P) {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= P.n_rays) return;
-    D3 org = d3(P.org[i * 3], P.org[i * 3 + 1], P.org[i * 3 + 2]);
-    D3 dir = d3(P.dir[i * 3], P.dir[i * 3 + 1], P.dir[i * 3 + 2]);
-    RngStream rng = P.key_override ? rng_open(rng_pixel_key(P.seed_mult, P.key_pixel), P.key_sample)
-                                   : rng_open(rng_pixel_key(P.seed_mult, (uint32_t)i), 0u);
-    PathCounters pc = {0, 0, 0};
-    int depth = 0;
-    bool overflow = false;
-    auto push = [&](int d, int id) {
-        if (d < RAY_MAX_DEPTH)
-            P.scratch[(size_t)d * P.n_rays + i] = (uint32_t)id;
-        else
-            overflow = true;
-    };
-    auto pop = [&](int d) -> int { return (int)P.scratch[(size_t)d * P.n_rays + i]; };
-    D3 term;
-    SceneGlobal sc;
-    sc.v = P.scene;
-    auto log_ray = [&]() {
-        if (P.trace && i == 0 && depth < P.trace_cap) {
-            double* t = P.trace + (size_t)depth * 6;
-            t[0] = org.x; t[1] = org.y; t[2] = org.z; t[3] = dir.x; t[4] = dir.y; t[5] = dir.z;
-        }
-    };
-    log_ray();
-    while (path_step<MathRef, 1>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push)) {
-        log_ray();
-        if (depth >= RAY_MAX_DEPTH) {
-            overflow = true;
-            term = d3(0, 0, 0);
-            break;
-        }
-    }
-    const D3 L = path_fold(sc, term, depth, pop);
-    P.out[i * 3] = L.x;
-    P.out[i * 3 + 1] = L.y;
-    P.out[i * 3 + 2] = L.z;
-    if (P.out_draws) P.out_draws[i] = pc.draws;
-    if (P.out_casts) P.out_casts[i] = pc.casts;
-    if (overflow) atomicOr(P.counters + 3, 1ull);
-}
-
-// Per-call seam: SphereObject::Intersect, pair i = (ray i, sphere i).
-__global__ __launch_bounds__(64) void intersect_pairs_kernel(const double4* __restrict__ geom,
-                                                             const double* __restrict__ org,
-                                                             const double* __restrict__ dir,
-                                                             size_t n, int mode,
-                                                             int32_t* __restrict__ out_hit,
-                                                             double* __restrict__ out_t,
-                                                             double* __restrict__ out_normal,
-                                                             const double* __restrict__ plane = nullptr) {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const D3 o = d3(org[i * 3], org[i * 3 + 1], org[i * 3 + 2]);
-    const D3 d = d3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]);
-    const double4 g = geom[i];
-    double t;
-    const bool is_plane = plane != nullptr && g.w < 0.0;
-    const bool hit = is_plane ? plane_test(plane + i * 16, o, d, t) : sphere_test<MathRef>(g, o, d, t);
-    out_hit[i] = hit ? 1 : 0;
-    if (hit) {
-        out_t[i] = t;
-        if (mode != RTM_MODE_LITERAL) {  // D2: literal mode never delivers the normal
-            const D3 nrm = is_plane ? d3(plane[i * 16 + 3], plane[i * 16 + 4], plane[i * 16 + 5])
-                                    : normalize((o + d * t) - d3(g.x, g.y, g.z));  // src/SettingData.cpp:214-215
-            out_normal[i * 3] = nrm.x;
-            out_normal[i * 3 + 1] = nrm.y;
-            out_normal[i * 3 + 2] = nrm.z;
-        }
-    }
-}
-
-__global__ void rng_batch_kernel(uint64_t seed_mult, uint32_t pixel0, uint32_t n_pixels,
-                                 uint32_t sample, uint32_t n_draws, double* __restrict__ out) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pixels) return;
-    RngStream s = rng_open(rng_pixel_key(seed_mult, pixel0 + p), sample);
-    for (uint32_t k = 0; k < n_draws; ++k) out[(size_t)p * n_draws + k] = rng_next(s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Component micro-benchmarks (profiles/component_bench.py): the nearest-hit loop and the shading
-// block in isolation, timed with s_memtime, same policies as the render kernel.
-// src/Renderer.cpp:58-73 as written, one lane per ray (SoA rays): the yardstick of rtm_debug_wf_nearest
-__global__ __launch_bounds__(256) void nearest_probe_kernel(SceneView scene, const double* __restrict__ org,
-                                                            const double* __restrict__ dir, unsigned n_rays,
-                                                            int* __restrict__ out_id, double* __restrict__ out_t) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    const unsigned r = i < n_rays ? i : n_rays - 1u;
-    SceneGlobal sc;
-    sc.v = scene;
-    double dis;
-    const int id = nearest_hit<MathRef, 1>(sc, d3(org[r], org[n_rays + r], org[2 * (size_t)n_rays + r]),
-                                           d3(dir[r], dir[n_rays + r], dir[2 * (size_t)n_rays + r]), dis);
-    if (i < n_rays) {
-        out_id[i] = id;
-        out_t[i] = dis;
-    }
-}
-
-template <class M, int UNROLL>
-__global__ __launch_bounds__(64) void nearest_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
-                                                           unsigned long long* cycles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    SceneGlobal sc;
-    sc.v = scene;
-    const int lane = threadIdx.x;
-    D3 dir = normalize(d3(-0.8 + 0.025 * (lane & 7) + 1e-3 * blockIdx.x, -0.5 + 0.12 * (lane >> 3), 1.0));
-    D3 org = org0;
-    double acc = 0.0;
-    int ids = 0;
-    unsigned long long t0, t1;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    for (int r = 0; r < reps; ++r) {
-        double dis;
-        const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
-        acc += dis;
-        ids += id;
-        org.x += 1e-7 * (id + 2);  // the next cast depends on this one, like a path
-    }
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    out[(size_t)blockIdx.x * 64 + lane] = acc + ids;
-    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
-    if (lds_raw[0] == 77 && reps < 0) out[0] = 1;  // keeps the dynamic LDS allocation alive
-}
-
-template <class M>
-__global__ __launch_bounds__(64) void shade_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
-                                                         unsigned long long* cycles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    SceneGlobal sc;
-    sc.v = scene;
-    const int lane = threadIdx.x;
-    D3 dir = normalize(d3(-0.8 + 0.025 * (lane & 7) + 1e-3 * blockIdx.x, -0.5 + 0.12 * (lane >> 3), 1.0));
-    D3 org = org0;
-    RngStream rng = rng_open(rng_pixel_key(12345, blockIdx.x * 64 + lane), 0);
-    PathCounters pc = {0, 0, 0};
-    double acc = 0.0;
-    unsigned long long t0, t1;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-    for (int r = 0; r < reps; ++r) {
-        int depth = 0;
-        D3 term;
-        // hit sphere 1 (a wall, kd 0.9) at a fixed distance: ~90 % of the lanes continue
-        bool cont;
-        if constexpr (std::is_same<M, MathFast>::value)
-            cont = path_shade_spec(sc, 1, 9.5 + 1e-3 * lane, RTM_MODE_REPAIRED, -1, org, dir, depth, rng, term, pc,
-                                   [](int, int) {});
-        else
-            cont = path_shade<M>(sc, 1, 9.5 + 1e-3 * lane, RTM_MODE_REPAIRED, -1, org, dir, depth, rng, term, pc,
-                                 [](int, int) {});
-        if (!cont) {
-            acc += term.x;
-            org = org0;
-        }
-        org.x *= 0.5;
-        org.y *= 0.5;
-        org.z = org.z * 0.5 - 5.0;
-    }
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    out[(size_t)blockIdx.x * 64 + lane] = acc + dir.x + org.y + pc.draws;
-    if (lane == 0) cycles[blockIdx.x] = t1 - t0;
-    if (lds_raw[0] == 77 && reps < 0) out[0] = 1;
-}
-
-// Exhaustive device-side self-checks (return the number of mismatching inputs).
-//   kind 0: sqrtf_fast == sqrtf for every float in [2^-96, FLT_MAX]
-// fp64 vector peak by wall clock (rtm_debug_fp64_peak; the stand-alone profiles/ubench/fp64_peak.hip has the whole
-// price list): every wave runs `iters` x 64 v_fma_f64 over 8 independent accumulators, `waves_per_simd` waves per SIMD
-// on every CU, no memory traffic in the loop.
-__global__ __launch_bounds__(256) void fp64_peak_kernel(double* out, int iters) {
-    double a0 = threadIdx.x * 1.0000001 + 1.5, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6,
-           a7 = a0 + 7;
-    const double b = 1.0000001, c = 0.5;
-    for (int i = 0; i < iters; ++i) {
-#define RTM_FMA8                                                                                                      \
-    asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"  \
-                 "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9"    \
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                     \
-                 : "v"(b), "v"(c));
-        RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8 RTM_FMA8
-#undef RTM_FMA8
-    }
-    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-}
-
-__global__ void selfcheck_kernel(int kind, unsigned long long* mismatches) {
-    const unsigned stride = gridDim.x * blockDim.x;
-    unsigned long long bad = 0;
-    if (kind == 0) {
-        for (unsigned long long b = 0x0F800000ull + blockIdx.x * blockDim.x + threadIdx.x; b < 0x7F800000ull; b += stride) {
-            const float x = __uint_as_float((unsigned)b);
-            if (!sqrtf_fast_ok(x) || __float_as_uint(sqrtf_fast(x)) != __float_as_uint(__builtin_sqrtf(x))) ++bad;
-        }
-        // outside the range the guard must say so
-        const float outside[6] = {0.0f, -1.0f, 1e-30f, __uint_as_float(0x7F800000u), __uint_as_float(0x7FC00000u), 1e-38f};
-        if (blockIdx.x == 0 && threadIdx.x == 0)
-            for (int i = 0; i < 6; ++i)
-                if (sqrtf_fast_ok(outside[i])) ++bad;
-    }
-    if (bad) atomicAdd(mismatches, bad);
-}
-
-// Device primitives exposed for parity tests of the building blocks (tests/test_device_math.py).
-__global__ void math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b,
-                                  size_t n, double* __restrict__ out, const uint32_t* __restrict__ fix = nullptr) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double x = a[i], y = b ? b[i] : 0.0;
-    double r = 0.0, s, c;
-    if (op >= 16 && op <= 18) {
-        // the draws of one bounce (RR, r1, r2) from the stream (ctr, k1) = (a, b), then the shading
-        // block's sincos of r1 corrected to the host libm: 16 -> r1, 17 -> sin, 18 -> cos
-        RngStream st{(uint32_t)x, (uint32_t)y};
-        (void)rng_next(st);
-        const double r1 = 6.283185307179586 * rng_next(st);
-        (void)rng_next(st);
-        sincos_small(r1, s, c);
-        apply_trig_fix(fix, st, s, c);
-        out[i] = op == 16 ? r1 : (op == 17 ? s : c);
-        return;
-    }
-    switch (op) {
-        case 0: r = sqrt(x); break;
-        case 1: r = (double)__builtin_sqrtf((float)x); break;
-        case 2: r = x / y; break;
-        case 3: r = sin(x); break;
-        case 4: r = cos(x); break;
-        case 5: sincos(x, &s, &c); r = s; break;
-        case 6: sincos(x, &s, &c); r = c; break;
-        case 7: r = x * y + 1.0; break;  // must NOT be contracted to an fma
-        case 8: r = MathFast::sqrt64(x); break;
-        case 12: sincos_small(x, s, c); r = s; break;
-        case 13: sincos_small(x, s, c); r = c; break;
-        case 14: { MathSpec m; r = m.sqrt64(x); if (m.bad) r = ::sqrt(x); } break;
-        case 15: { MathSpec m; r = m.div3(d3(x, 1.0, -x), y).x; if (m.bad) r = x / y; } break;
-        case 9: r = MathFast::div3(d3(x, x * 0.5, -x), y).x; break;
-        case 10: r = MathFast::div3(d3(1.0, x, 0.0), y).y; break;
-        case 11: r = MathFast::div3(d3(y, -0.0, x), y).z; break;
-    }
-    out[i] = r;
-}
 
 // ================================================================================================
 // Host side of the device path
@@ -2134,9 +1069,19 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const unsigned slots = (unsigned)cus * 16u;
     const SplitPlan none{1u, 0u, total_samples};
-    // wave 0 keeps half of the samples (its terms never leave the chip, and it starts in the launch's first rounds, so
-    // the small waves still set the tail: profiles/r2/tail_split.txt, h = 8 of 16); an odd g: the larger half
-    auto head_of = [&](unsigned g) { return g >= 4 ? (total_samples / g) * ((g + 1u) / 2u) : total_samples / g; };
+    // wave 0 keeps about half of the samples (its terms never leave the chip, and it starts in the launch's first rounds,
+    // so the small waves still set the tail: profiles/r2/tail_split.txt); an odd g: the larger half
+    static const long env_head = [] {
+        const char* e = std::getenv("RTM_DEBUG_HEAD");  // tuning knob: wave 0 keeps this many of g shares (default: half)
+        return e ? std::strtol(e, nullptr, 10) : 0L;
+    }();
+    auto head_of = [&](unsigned g) {
+        if (env_head > 0 && (unsigned)env_head < g) return (total_samples / g) * (unsigned)env_head;
+        // 9 of 16 shares: as fast as 8 (headline 170.8 / 170.6 ms, 512x512x256spp 6.68 / 6.72, one GPU's share of eight equal),
+        // an eighth fewer terms to store; 10 of 16 costs the headline frame 0.5 % (profiles/r3/head_ab.txt)
+        if (g % 16u == 0u) return (total_samples / g) * (9u * (g / 16u));
+        return g >= 4 ? (total_samples / g) * ((g + 1u) / 2u) : total_samples / g;
+    };
     auto valid_g = [&](unsigned g) {
         return g >= 2 && total_samples % g == 0 && total_samples / g >= 8 && total_samples / g <= kSplitMaxLen;
     };
