@@ -2,7 +2,10 @@
     python profiles/fuzz_parity.py <seed> <cases> <host_trig 0|1>
 Random scene size and kind (open stress scene / closed box packed with small spheres), image shape,
 S, SS, bounce cap (0 .. 200 or unlimited), mode and kernel variant; every frame and its counters are
-compared with the oracle bit for bit.  Results of round 1 in profiles/r1/fuzz_parity.txt."""
+compared with the oracle bit for bit.  Round 3: every fourth case is a scene with png::PlaneObject entries (axis-aligned and
+tilted squares among spheres inside a room sphere; variants 0, 1, 2, 9), and a third of the cases go through the
+enqueue-only entry point (rtm_render_scene without rtm_stats: sticky status, fixed trip budget of the large-scene
+pipeline) instead of the blocking one.  Results: profiles/r1/, r2/, r3/fuzz_parity.txt."""
 import os
 import sys
 
@@ -26,8 +29,31 @@ bad = 0
 for case in range(cases):
     n = int(rng.choice([1, 2, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
                         513, 1000]))
-    kind = case % 3
-    if kind == 0:
+    kind = case % 4
+    if kind == 3:  # planes and spheres mixed, in a room
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 24, 25, 40, 100, 254]))
+        objs = []
+        for k in range(n):
+            col = rtm.vec3(*map(float, rng.uniform(0.2, 0.9, 3)))
+            em = rtm.vec3(3.0, 3.0, 3.0) if k % 6 == 0 else rtm.vec3(0, 0, 0)
+            pos = rtm.vec3(*map(float, rng.uniform(-6, 6, 3)))
+            t = int(rng.integers(3))
+            if t == 0:
+                objs.append(rtm.SphereObject(pos, float(rng.uniform(0.3, 2.0)), rtm.Material(col, em)))
+            elif t == 1:  # axis-aligned square facing the middle of the room: exact zeros in its normal
+                axis = int(rng.integers(3))
+                tgt = [pos.x, pos.y, pos.z]
+                tgt[axis] += 1.0 if tgt[axis] < 0 else -1.0
+                up = rtm.vec3(0, 0, 1) if axis == 1 else rtm.vec3(0, 1, 0)
+                objs.append(rtm.PlaneObject(pos, up, rtm.vec3(*tgt), float(rng.uniform(1, 9)), rtm.Material(col, em)))
+            else:
+                objs.append(rtm.PlaneObject(pos, rtm.vec3(0.1, 1, 0.2), rtm.vec3(*map(float, rng.uniform(-2, 2, 3))),
+                                            float(rng.uniform(1, 9)), rtm.Material(col, em)))
+        objs.append(rtm.SphereObject(rtm.vec3(0, 0, 0), 25.0, rtm.Material(rtm.vec3(0.7, 0.7, 0.7), rtm.vec3(0.3, 0.3, 0.3))))
+        n = len(objs)
+        cam = rtm.Camera(rtm.vec3(0, 0, -11), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.2)
+        data = rtm.SettingData(width=8, height=8, samples=1, superSamples=1, camera=cam, object=objs)
+    elif kind == 0:
         objs = list(box.object)[: max(1, min(n, 7))]
         while len(objs) < n:
             objs.append(sphere(rng.uniform(-7, 7, 3), float(rng.uniform(0.3, 1.0)), rng.uniform(0.2, 0.9, 3)))
@@ -39,21 +65,36 @@ for case in range(cases):
     mb = int(rng.choice([-1, -1, 0, 1, 2, 7, 8, 9, 15, 16, 17, 40, 200]))
     mode = "literal" if case % 5 == 4 else "repaired"
     seed = int(rng.integers(1 << 40))
-    variant = int(rng.choice([0, 0, 0, 2, 9, 13, 14, 3, 12]))
+    variant = int(rng.choice([0, 0, 0, 2, 9, 14, 3, 12]))
     if case % 7 == 3 and 1 <= n <= 24 and 0 <= mb <= 8 and mode == "repaired":
         variant = 15  # the labelled primary-hit-reuse row must give the same bits where it applies
-    st, arr, cnt_n = data.to_c()
-    ost = oracle.Settings.from_buffer_copy(bytes(st))
-    oarr = (oracle.Sphere * max(cnt_n, 1)).from_buffer_copy(bytes(arr))
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED
-    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
+    if data.has_planes():
+        variant = int(rng.choice([0, 0, 1, 2, 9]))
+        oarr_c, cnt_n = data.objects_c()
+        oobj = (oracle.Object * max(cnt_n, 1)).from_buffer_copy(bytes(oarr_c))
+        ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))
+        ref, cnt = oracle.render_objects(ost, oobj, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
+    else:
+        st, arr, cnt_n = data.to_c()
+        ost = oracle.Settings.from_buffer_copy(bytes(st))
+        oarr = (oracle.Sphere * max(cnt_n, 1)).from_buffer_copy(bytes(arr))
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
     r = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=variant, host_trig=host_trig)
-    out, stats = r.render_rows(0, data.height, want=("f64",))
-    ok = np.array_equal(out["f64"], ref, equal_nan=True) and \
-        (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"])
+    if case % 3 == 1:  # the enqueue-only entry point: no rtm_stats, the stream's sticky status afterwards
+        import torch
+        dev_out, _ = r.render_rows_device(0, data.height, want=("f64",), stats=False)
+        torch.cuda.synchronize()
+        r.stream_status()
+        ok = np.array_equal(dev_out["f64"].cpu().numpy(), ref, equal_nan=True)
+        out = {"f64": dev_out["f64"].cpu().numpy()}
+    else:
+        out, stats = r.render_rows(0, data.height, want=("f64",))
+        ok = np.array_equal(out["f64"], ref, equal_nan=True) and \
+            (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"])
     if not ok:
         bad += 1
-        print("MISMATCH case", case, dict(n=n, closed_box=kind == 0, w=data.width, h=data.height, S=data.samples,
+        print("MISMATCH case", case, dict(n=n, kind=("closed box", "stress", "stress", "planes")[kind], w=data.width, h=data.height, S=data.samples,
                                           SS=data.superSamples, max_bounces=mb, mode=mode, variant=variant),
               "max pixel delta", float(np.nanmax(np.abs(out["f64"] - ref))))
 print("seed", seed0, "cases", cases, "host_trig", host_trig, "frames differing from the oracle:", bad)
