@@ -647,7 +647,10 @@ def test_one_pixel_one_sample(rtm, oracle):
 @pytest.mark.parametrize("w,h,s,ss,mb", [(64, 40, 8, 2, 8),    # split on sub-pixel boundaries
                                           (45, 27, 8, 3, 8),    # 72 samples: ranges start inside a sub-pixel
                                           (40, 24, 24, 1, -1),  # unlimited depth (LDS records + pool)
-                                          (33, 17, 5, 2, 12)])  # 20 samples: two waves of 10
+                                          (33, 17, 5, 2, 12),   # 20 samples: two waves of 10
+                                          (40, 24, 125, 2, 8),  # 500 samples: 20 shares of 25 (not a power of two)
+                                          (24, 16, 5, 3, 8),    # 45 samples: 5 shares of 9, an odd count: wave 0 keeps 3
+                                          (16, 16, 256, 4, 8)])  # 4096 samples: 64 shares of 64, 29 waves per tile
 def test_sample_split_is_bit_identical(rtm, oracle, w, h, s, ss, mb):
     """Several waves per tile, each tracing a range of the pixel's samples; the terms are added in the
     reference's order afterwards (src/Renderer.cpp:241-242), so nothing may change."""
