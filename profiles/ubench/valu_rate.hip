@@ -1,3 +1,9 @@
+// SUPERSEDED (round 3) by profiles/ubench/fp64_peak.hip, which times whole chip-filling launches with HIP events.  This file
+// reads s_memtime around the loop of ONE wave per block; under the SIMD's oldest-first issue that wave runs ahead of its three
+// neighbours (fp64_peak.hip measures it: wave 0 is done after 32 % of the launch at 4 waves per SIMD, 16 % at 8), so its "ticks
+// per instruction" are not a unit of the SIMD's issue rate and cannot be calibrated into one.  Kept for the relative order it
+// showed in round 1 (profiles/r1/ubench_valu_rate.txt).
+//
 // valu_rate.hip — issue cost (cycles per wave64 instruction per SIMD) of the VALU instructions the
 // render kernel is made of, measured with s_memtime on gfx950.  Build & run (GPU box):
 //   hipcc -O2 --offload-arch=gfx950 profiles/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
