@@ -1230,6 +1230,8 @@ static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, bool m
         if (b >= 1) {  // batch b is queued: now look at what batch b-1 left
             RTM_HIP_CHECK(hipEventSynchronize(ev.e[(b - 1) & 1]));
             na = ctx.wf_count_host[(b - 1) & 1];
+            static const bool trace = std::getenv("RTM_DEBUG_WF_TRACE") != nullptr;  // diagnostic: the active count, batch by batch
+            if (trace) std::fprintf(stderr, "[rtm wf] trips %llu active %u\n", trip, na);
             if (na == 0) break;
         }
     }
