@@ -147,115 +147,123 @@ def valu_issue_view(pmc, source):
 
 
 def other_configs(rtm, cfg, device, host_trig, full_c5=True):
-    """BASELINE configs[1], configs[4] (the full frame unless --no-full-c5, and a strip) and the plane scene, measured in
-    this run, outside the timed region."""
+    """BASELINE configs[1], configs[4] (the full frame unless --no-full-c5, and a strip), the plane scene and the two
+    labelled rows, measured in this run, outside the timed region.  Every group of rows stands alone: a failure is
+    recorded under its name and the others are still measured."""
     import torch
     out = {"measured_in_run": True}
-    data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
-    data.width, data.height, data.samples, data.superSamples = 512, 512, 16, 4
-    for name, mb in (("c2_cornell_512x512_256spp_max8", 8), ("c2_cornell_512x512_256spp_unlimited", -1)):
-        r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=cfg["seed"], device=device, host_trig=host_trig)
-        r.render_rows_device(want=("f32",), stats=True)
+
+    def timed(r, steps, **kw):
+        r.render_rows_device(want=("f32",), stats=True, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
-            r.render_rows_device(want=("f32",), stats=False)
+        for _ in range(steps):
+            r.render_rows_device(want=("f32",), stats=False, **kw)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
-        _, st = r.render_rows_device(want=("f32",), stats=True)
-        out[name] = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 5,
-                     "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-                     "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"]}
-    # SEPARATELY LABELLED row (SURVEY.md §8d): the headline frame with the primary hit of a sub-pixel computed once
-    # for its S samples (variant 15) — same image and counters, less work per sample than the reference does
-    data.width, data.height, data.samples, data.superSamples = cfg["width"], cfg["height"], cfg["samples"], cfg["super_samples"]
-    r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
-                     host_trig=host_trig, variant=15)
-    r.render_rows_device(want=("f32",), stats=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        r.render_rows_device(want=("f32",), stats=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    _, st = r.render_rows_device(want=("f32",), stats=True)
-    out["LABELLED_headline_frame_with_primary_hit_reuse"] = {
-        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-        "kernel_ms": st["kernel_ms"], "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-        "note": "not comparable with the headline value or the CPU baseline: one nearest-hit search per sub-pixel "
-                "instead of one per sample for the primary ray (the reference repeats it, src/Renderer.cpp:224-238)"}
-    # SEPARATELY LABELLED row: single precision with the hardware's sqrt / sin / cos (variant 16) — not a parity path;
-    # reported with the fraction of pixels that leave the north_star tolerance against the fp64 frame of this run
-    exact_frame, _ = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
-                                  host_trig=host_trig).render_rows_device(want=("f32",), stats=True)
-    r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device, variant=16)
-    fast_frame, _ = r.render_rows_device(want=("f32",), stats=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        r.render_rows_device(want=("f32",), stats=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    _, st = r.render_rows_device(want=("f32",), stats=True)
-    delta = (fast_frame["f32"].double() - exact_frame["f32"].double()).abs()
-    out["LABELLED_headline_frame_fp32_fast_NOT_PARITY"] = {
-        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-        "kernel_ms": st["kernel_ms"], "dtype": "f32", "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-        "pixels_outside_1e-4_of_the_fp64_frame": float((delta.amax(dim=2) > 1e-4).double().mean()),
-        "max_abs_delta": float(delta.max()), "mean_abs_delta": float(delta.mean()),
-        "note": "float arithmetic, v_sqrt/v_rsq/v_sin/v_cos, fused multiply-adds, forward throughput: a sample whose ray "
-                "grazes a silhouette may take another path than the reference's; not comparable with the headline value"}
-    # scenes/planeRoom.json (png::PlaneObject completed as a finite square, DESIGN.md §9) at 1080p x 256 spp: the chunked
-    # LDS-table kernel with the plane test in its object chunk (SURVEY.md §8f row 4)
-    room = rtm.LoadData(os.path.join(ROOT, "scenes", "planeRoom.json")).data
-    room.width, room.height, room.samples, room.superSamples = 1920, 1080, 16, 4
-    r = rtm.Renderer(room, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
-    r.render_rows_device(want=("f32",), stats=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        r.render_rows_device(want=("f32",), stats=False)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    _, st = r.render_rows_device(want=("f32",), stats=True)
-    out["plane_room_1080p_256spp_max8"] = {
-        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-        "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-        "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"],
-        "note": "6 planes + 2 spheres; not a reference scene (the reference's PlaneObject::Intersect is unfinished)"}
-    stress = rtm.make_stress_scene(n=100_000, seed=12345)
-    stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
-    r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
-    r.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: scene upload, buffers
-    t0 = time.perf_counter()
-    _, st = r.render_rows_device(508, 572, want=("f32",), stats=True)
-    dt = time.perf_counter() - t0
-    tests_per_s = st["casts"] * 100_000 / dt
-    out["c5_stress_100k_rows_508_572_of_1080p_256spp"] = {
-        "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
-        "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-        "sphere_tests_per_s": tests_per_s,
-        "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-        "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-        "note": "a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the chip "
-                "(DESIGN.md §4)"}
-    if full_c5:
-        # BASELINE configs[4] as named: the whole 1080p frame at 256 spp, one timed step (~25 s)
-        t0 = time.perf_counter()
-        _, st = r.render_rows_device(want=("f32",), stats=True)
-        dt = time.perf_counter() - t0
-        tests_per_s = st["casts"] * 100_000 / dt
-        row = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
-               "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-               "sphere_tests_per_s": tests_per_s,
-               "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-               "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "traffic": None}
-        tpath = os.path.join(ROOT, "profiles", "r3", "c5_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            row["traffic"] = tj["bytes_per_frame"]
-            row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_traffic.json", "note": tj.get("note")}
-        out["c5_stress_100k_full_1080p_256spp"] = row
+        dt = (time.perf_counter() - t0) / steps
+        _, st = r.render_rows_device(want=("f32",), stats=True, **kw)
+        return dt, st
+
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001 — the bench line must come out; the failure is named in it
+            out[name] = {"error": repr(exc)}
+
+    def c2():
+        data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
+        data.width, data.height, data.samples, data.superSamples = 512, 512, 16, 4
+        for name, mb in (("c2_cornell_512x512_256spp_max8", 8), ("c2_cornell_512x512_256spp_unlimited", -1)):
+            r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=cfg["seed"], device=device, host_trig=host_trig)
+            dt, st = timed(r, 5)
+            out[name] = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 5,
+                         "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+                         "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"]}
+
+    def headline_data():
+        data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
+        data.width, data.height, data.samples, data.superSamples = cfg["width"], cfg["height"], cfg["samples"], cfg["super_samples"]
+        return data
+
+    def reuse_row():
+        # SEPARATELY LABELLED row (SURVEY.md §8d): the headline frame with the primary hit of a sub-pixel computed once
+        # for its S samples (variant 15) — same image and counters, less work per sample than the reference does
+        r = rtm.Renderer(headline_data(), mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+                         host_trig=host_trig, variant=15)
+        dt, st = timed(r, 3)
+        out["LABELLED_headline_frame_with_primary_hit_reuse"] = {
+            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+            "kernel_ms": st["kernel_ms"], "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
+            "note": "not comparable with the headline value or the CPU baseline: one nearest-hit search per sub-pixel "
+                    "instead of one per sample for the primary ray (the reference repeats it, src/Renderer.cpp:224-238)"}
+
+    def fp32_row():
+        # SEPARATELY LABELLED row: single precision with the hardware's sqrt / sin / cos (variant 16) — not a parity path;
+        # reported with the fraction of pixels that leave the north_star tolerance against the fp64 frame of this run
+        data = headline_data()
+        exact_frame, _ = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+                                      host_trig=host_trig).render_rows_device(want=("f32",), stats=True)
+        r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device, variant=16)
+        fast_frame, _ = r.render_rows_device(want=("f32",), stats=True)
+        dt, st = timed(r, 3)
+        delta = (fast_frame["f32"].double() - exact_frame["f32"].double()).abs()
+        out["LABELLED_headline_frame_fp32_fast_NOT_PARITY"] = {
+            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+            "kernel_ms": st["kernel_ms"], "dtype": "f32", "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
+            "pixels_outside_1e-4_of_the_fp64_frame": float((delta.amax(dim=2) > 1e-4).double().mean()),
+            "max_abs_delta": float(delta.max()), "mean_abs_delta": float(delta.mean()),
+            "note": "float arithmetic, v_sqrt/v_rsq/v_sin/v_cos, fused multiply-adds, forward throughput: a sample whose ray "
+                    "grazes a silhouette may take another path than the reference's; not comparable with the headline value"}
+
+    def plane_room():
+        # scenes/planeRoom.json (png::PlaneObject completed as a finite square, DESIGN.md §9) at 1080p x 256 spp: the chunked
+        # LDS-table kernel with the plane test in its object chunk (SURVEY.md §8f row 4)
+        room = rtm.LoadData(os.path.join(ROOT, "scenes", "planeRoom.json")).data
+        room.width, room.height, room.samples, room.superSamples = 1920, 1080, 16, 4
+        r = rtm.Renderer(room, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
+        dt, st = timed(r, 3)
+        out["plane_room_1080p_256spp_max8"] = {
+            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+            "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+            "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"],
+            "note": "6 planes + 2 spheres; not a reference scene (the reference's PlaneObject::Intersect is unfinished)"}
+
+    def c5():
+        stress = rtm.make_stress_scene(n=100_000, seed=12345)
+        stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
+        r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
+        r.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: scene upload, buffers
+
+        def c5_row(lo, hi):
+            t0 = time.perf_counter()
+            _, st = r.render_rows_device(lo, hi, want=("f32",), stats=True)
+            dt = time.perf_counter() - t0
+            tests_per_s = st["casts"] * 100_000 / dt
+            return {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
+                    "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+                    "sphere_tests_per_s": tests_per_s,
+                    "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
+                    "variant": rtm.lib().rtm_variant_name(st["variant"]).decode()}
+        row = c5_row(508, 572)
+        row["note"] = ("a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the "
+                       "chip (DESIGN.md §4)")
+        out["c5_stress_100k_rows_508_572_of_1080p_256spp"] = row
+        if full_c5:
+            # BASELINE configs[4] as named: the whole 1080p frame at 256 spp, one timed step (~23 s)
+            row = c5_row(0, 1080)
+            row["traffic"] = None
+            tpath = os.path.join(ROOT, "profiles", "r3", "c5_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                row["traffic"] = tj["bytes_per_frame"]
+                row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_traffic.json", "note": tj.get("note")}
+            out["c5_stress_100k_full_1080p_256spp"] = row
+
+    guarded("c2_cornell_512x512_256spp", c2)
+    guarded("LABELLED_headline_frame_with_primary_hit_reuse", reuse_row)
+    guarded("LABELLED_headline_frame_fp32_fast_NOT_PARITY", fp32_row)
+    guarded("plane_room_1080p_256spp_max8", plane_room)
+    guarded("c5_stress_100k", c5)
     return out
 
 
@@ -489,10 +497,14 @@ def main():
         cps = stats["casts"] / stats["samples"]
         bps = stats["bounces"] / stats["samples"]
         cpu = None
+        extras_failed = {}
         d4 = 0.93
         if world == 1 and args.cpu_rows > 0:
-            cpu = cpu_baseline(cfg, args.cpu_rows)
-            d4 = cpu["d4_fraction"]
+            try:
+                cpu = cpu_baseline(cfg, args.cpu_rows)
+                d4 = cpu["d4_fraction"]
+            except Exception as exc:  # the headline line must come out whatever an extra does; the failure is named in it
+                cpu, extras_failed = None, {"cpu_baseline": repr(exc)}
         f_sample = algorithmic_flops_per_sample(n_spheres, cps, bps, d4)
         rank_samples = stats["samples"]  # samples one launch of this rank processed
         flops_per_launch = f_sample * rank_samples
@@ -549,9 +561,12 @@ def main():
         if world == 1 and headline and args.variant == 0 and ppath:
             line["roofline"]["valu_issue"] = valu_issue_view(json.load(open(ppath)), os.path.relpath(ppath, ROOT))
         if world == 1 and not args.no_extras:
-            pk = measured_fp64_peak(rtm)
-            line["roofline"]["peak_measured"] = pk
-            line["roofline"]["frac_of_measured_peak"] = achieved_tflops / pk["value"]
+            try:
+                pk = measured_fp64_peak(rtm)
+                line["roofline"]["peak_measured"] = pk
+                line["roofline"]["frac_of_measured_peak"] = achieved_tflops / pk["value"]
+            except Exception as exc:
+                extras_failed["peak_measured"] = repr(exc)
             line["roofline"]["peak_source"] = "AMD datasheet, FP64 vector 78.6 TFLOP/s (MI355X_MICROARCH.md lists fp32 157.3 only)"
         if n_spheres >= 512 and args.variant in (0, 12):
             # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
@@ -578,7 +593,12 @@ def main():
                                 "what": "the same K steps with the gathered frame copied to pinned host memory each step "
                                         "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
         if world == 1 and not args.no_extras and headline:
-            line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=not args.no_full_c5)
+            try:
+                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=not args.no_full_c5)
+            except Exception as exc:
+                extras_failed["other_configs"] = repr(exc)
+        if extras_failed:
+            line["extras_failed"] = extras_failed
         print(json.dumps(line), flush=True)
     if use_group:
         dog.enter("destroy_process_group")
