@@ -753,8 +753,9 @@ static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream
             <<<grid, 64, tab + kFoldQueueBytesL + tag, stream>>>(P);
 }
 
+constexpr size_t kStealLdsBytes = 2 * 64 * sizeof(unsigned);  // STEAL: every pixel's next own sample and own-sample end
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
-          bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false>
+          bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false, bool STEAL = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad() + (SPLIT ? kFoldTagBytes : 0);
@@ -766,8 +767,8 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
                 switch (P.scene.n) {
 #define RTM_EXACT_N(k)                                                                                     \
     case k:                                                                                                \
-        render_tiles_kernel<M, LDS_TAB, -100 - k, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>           \
-            <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);                                              \
+        render_tiles_kernel<M, LDS_TAB, -100 - k, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL> \
+            <<<grid, 64, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0), stream>>>(P);               \
         return;
                     RTM_EXACT_N(1) RTM_EXACT_N(2) RTM_EXACT_N(3) RTM_EXACT_N(4) RTM_EXACT_N(5) RTM_EXACT_N(6) RTM_EXACT_N(7)
 #undef RTM_EXACT_N
@@ -775,8 +776,8 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
                 }
             }
             if constexpr (DEFER)
-                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true>
-                    <<<grid, 64, tab + kFoldQueueBytes, stream>>>(P);
+                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL>
+                    <<<grid, 64, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0), stream>>>(P);
             else
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, false><<<grid, 64, tab, stream>>>(P);  // (never split: the split rides on the fold queue)
             return;
@@ -815,6 +816,20 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
                 } else {
                     launch_render_planes<false>(P, grid, stream);
                 }
+                return;
+            }
+            if (P.steal_ws != nullptr) {  // render_view: depth cap <= 8; the whole tiles balance their lanes by sample stealing
+                if (P.split > 1) {
+                    if (n < 8) launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, true, true, true>(P, split_grid, stream);
+                    else launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, true, true, true>(P, split_grid, stream);
+                    split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
+                } else if (n < 8) {
+                    launch_render_depth<MathFast, true, -8, uint8_t, 4, true, false, true, false, true, true>(P, grid, stream);
+                } else {
+                    launch_render_depth<MathFast, true, 8, uint8_t, 4, true, false, true, false, true, true>(P, grid, stream);
+                }
+                const unsigned n_whole = P.split > 1 ? P.split_first : grid;
+                if (n_whole) steal_finalize_kernel<<<n_whole, 64, (size_t)P.steal_depth * 64 * sizeof(unsigned short), stream>>>(P);
                 return;
             }
             if (P.split > 1) {
@@ -875,7 +890,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
 // naming the same (device, stream) take turns and never see each other's half-grown buffers; `g_gate` is
 // held shared by every render and exclusively by release_scratch, which therefore never frees anything
 // under a call that is between acquiring a buffer and launching on it.
-enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchRoles = 3 };
+enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchSteal = 3, kScratchRoles = 4 };
 namespace {
 struct ScratchBuf {
     void* ptr = nullptr;
@@ -1405,6 +1420,33 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                 P.split_first = 0;
                 P.split_len = P.split_head = P.total_samples;
             }
+        }
+    }
+    // In-wave sample stealing for the whole tiles of the packed-record LDS-table kernel (rtm_render_kernel.h, STEAL): a
+    // block per whole tile for the accumulators and the stolen samples' terms.  Rows per tile: the stolen share of a tile
+    // shrinks like 1 / sqrt(samples) (2.2 % of 64 x 1024 samples, 4.5 % of 64 x 256), i.e. ~0.7 sqrt(spp) rows; capacity
+    // is three times that.  Without room for the blocks the launch runs without stealing (same image).
+    static const bool steal_off = [] {
+        const char* e = std::getenv("RTM_DEBUG_STEAL");  // tuning knob: 0 = no sample stealing
+        return e && e[0] == '0';
+    }();
+    if (!steal_off && variant == kVariantFastLds && view.plane == nullptr && n >= 1 && n < 256 /* packed records: PACK8 */ &&
+        P.max_bounces >= 0 && P.max_bounces <= 8 && P.total_samples >= 16 && P.total_samples < 65536u && st->samples < 65536 &&
+        opt->variant != kVariantFastLds /* explicit variant 2 stays the plain kernel: the A/B twin */) {
+        const unsigned n_whole = P.split > 1 ? P.split_first : grid;
+        unsigned rows = 2u * (unsigned)std::ceil(std::sqrt((double)P.total_samples)) + 4u;
+        rows = rows < 8u ? 8u : (rows > 68u ? 68u : rows);
+        unsigned depth = P.total_samples / 2u;
+        depth = depth > 256u ? 256u : depth;
+        void* ws = nullptr;
+        if (n_whole != 0 && scratch_acquire(ctx, kScratchSteal, (size_t)n_whole * steal_tile_bytes(rows), &ws) == RTM_OK) {
+            P.steal_ws = static_cast<unsigned char*>(ws);
+            P.steal_rows = rows;
+            P.steal_depth = depth;
+            P.magic_S = (unsigned)(0x100000000ull / (unsigned long long)st->samples) + 1u;
+            P.magic_SS = (unsigned)(0x100000000ull / (unsigned long long)st->super_samples) + 1u;
+        } else {
+            (void)hipGetLastError();
         }
     }
     // deep-path record pool.  Kernels with an LDS record stack take a slot only for the

@@ -44,8 +44,17 @@ struct RenderParams {
     // per-sample terms of waves 1..: one block of split_len rows per (tile, small wave), a row = 64 terms in the order
     // the wave FOLDED them ([3][64] doubles, whole lines from one store instruction) + 64 tags (owner lane, sample)
     unsigned char* __restrict__ contrib;
+    // in-wave sample stealing (STEAL kernels, whole tiles): per tile a block of kStealHdrBytes (terms stored, every
+    // pixel's final own-sample end) + 3 x 64 doubles (the accumulators) + steal_rows rows of kStealRowBytes (64 terms in
+    // fold order + 64 four-byte tags (pixel lane, sample)); steal_finalize_kernel turns the block into pixels
+    unsigned char* __restrict__ steal_ws;
+    unsigned steal_rows, steal_depth;  // capacity in rows per tile; how far below the last sample a pixel may be stolen from
+    unsigned magic_S, magic_SS;        // floor(2^32 / d) + 1: x / d == umulhi(x, magic) for x, d < 2^16 (a stolen sample's sub-pixel)
 };
 constexpr size_t kTermRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned short);  // 1664 = 13 lines of 128 B
+constexpr size_t kStealRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned);       // 1792 = 14 lines of 128 B
+constexpr size_t kStealHdrBytes = 256;                                                    // unsigned n_terms; ...; u16 end[64] at +128
+__host__ __device__ inline size_t steal_tile_bytes(unsigned rows) { return kStealHdrBytes + 3 * 64 * sizeof(double) + (size_t)rows * kStealRowBytes; }
 
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -205,12 +214,22 @@ constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  /
 // wave — 15 instead of 16 waves per CU, 5 % on every unlimited-depth frame, profiles/r3/ab_r2_vs_r3.txt.)
 constexpr size_t kFoldTagBytes = 0;
 
+//   STEAL   (with DEFER + PACK8) in-wave sample stealing for WHOLE tiles.  All 64 lanes of a wave trace the same number of
+//           samples but not the same number of casts, so a wave runs until its slowest lane is done: 4.4 % of the lane-trips
+//           of the headline frame are spent by lanes that have finished (8.9 % at 256 spp, 15 % at 64 spp:
+//           profiles/r3/ragged_end.txt).  When the first lane runs out of samples the wave leaves the main loop for a
+//           TAIL loop in which a lane without own samples takes the LAST unstarted sample of the pixel that has most left
+//           (wave-uniform choice, no atomics: one victim per trip), traces it — the RNG is keyed by (pixel, sample) — and
+//           leaves its clamped term, tagged (pixel, sample), in the tile's row buffer in HBM; a pixel's own lane
+//           accumulates samples [0, end) in order as before, and steal_finalize_kernel adds the stolen terms [end, total)
+//           in order on top.  Only the ORDER of the additions is observable, and it is the reference's.
 //   PLANES  (with LDS_TAB) the scene holds png::PlaneObject entries: SceneLdsObjects / object_chunk / MathSpecZ
 //           (rtm_path.h) — a plane's test in its index slot of the chunk, its normal from the LDS table
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int LDS_D, int WPE = 1, bool PARK = false,
           bool STAMP = false, bool PACK8 = false, bool SPLIT = false, bool DEFER = false, bool PACKL = false,
-          bool REUSE = false, bool PLANES = false>
+          bool REUSE = false, bool PLANES = false, bool STEAL = false>
 __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParams P) {
+    static_assert(!STEAL || (DEFER && PACK8 && !REUSE && !PACKL), "sample stealing rides on the deferred fold with packed records");
     static_assert(!PLANES || (LDS_TAB && !REUSE), "plane scenes ride on the LDS tables");
     static_assert(!SPLIT || DEFER, "the sample split's small waves store their terms from the fold queue");
     static_assert(!DEFER || ((PACK8 || PACKL) && PARK && !STAMP), "the fold queue rides on packed records and the LDS accumulator");
@@ -363,8 +382,16 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     // DEFER: ring indices (wave-uniform) and one pass of the queue
     unsigned fq_head = 0, fq_tail = 0, fq_count = 0;
-    auto fold_pass = [&](auto small_tag) {
-        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
+    // what a lane of the STEAL tail loop folded in this pass, kept for the export behind the per-lane part
+    D3 tail_add = d3(0, 0, 0);
+    unsigned tail_tag = 0u;
+    unsigned stolen_out = 0u;  // STEAL: terms this wave has exported (wave-uniform)
+    // MODE 0: whole / head waves, 1: small waves of the sample split, 2: the STEAL tail loop
+    auto fold_pass = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool SMALL = SPLIT && MODE == 1;
+        constexpr bool TAIL = STEAL && MODE == 2;
+        if constexpr (TAIL) tail_tag = 0u;
         const unsigned m = fq_count < 64u ? fq_count : 64u;
         if ((unsigned)lane < m) {
             const unsigned at = (fq_head + (unsigned)lane) & (kFoldRing - 1);
@@ -403,9 +430,34 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     if ((e.z >> 8) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
                 }
             } else {
-                fq_out[0 * 64 + lane] = add.x;
-                fq_out[1 * 64 + lane] = add.y;
-                fq_out[2 * 64 + lane] = add.z;
+                if constexpr (TAIL) {
+                    tail_add = add;
+                    tail_tag = e.w;  // 0: the owner's own sample; else 0x80000000 | pixel lane << 16 | sample
+                }
+                if (!TAIL || e.w == 0u) {
+                    fq_out[0 * 64 + lane] = add.x;
+                    fq_out[1 * 64 + lane] = add.y;
+                    fq_out[2 * 64 + lane] = add.z;
+                }
+            }
+        }
+        if constexpr (TAIL) {
+            // stolen samples' terms leave the chip in fold order, densely packed into the tile's rows (non-temporal)
+            const bool out = tail_tag != 0u;
+            const unsigned long long m_out = __builtin_amdgcn_ballot_w64(out);
+            if (m_out != 0ull) {
+                if (out) {
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_out >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_out, 0u));
+                    const unsigned pos = stolen_out + rank;
+                    unsigned char* row = P.steal_ws + (size_t)blockIdx.x * steal_tile_bytes(P.steal_rows) + kStealHdrBytes +
+                                         3 * 64 * sizeof(double) + (size_t)(pos >> 6) * kStealRowBytes;
+                    double* v = reinterpret_cast<double*>(row) + (pos & 63u);
+                    __builtin_nontemporal_store(tail_add.x, v);
+                    __builtin_nontemporal_store(tail_add.y, v + 64);
+                    __builtin_nontemporal_store(tail_add.z, v + 128);
+                    __builtin_nontemporal_store(tail_tag & 0x7FFFFFFFu, reinterpret_cast<unsigned*>(row + 3 * 64 * sizeof(double)) + (pos & 63u));
+                }
+                stolen_out += (unsigned)__builtin_popcountll(m_out);
             }
         }
         if constexpr (SMALL) {
@@ -429,13 +481,18 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         }
         fq_head = (fq_head + m) & (kFoldRing - 1);
         fq_count -= m;
-        // a small wave's queue has run empty: none of its lanes has an entry waiting, deep or not
-        (void)small_tag;
+        (void)mode_tag;
     };
+    using ModeWhole = std::integral_constant<int, 0>;
+    using ModeSmall = std::integral_constant<int, 1>;
+    using ModeTail = std::integral_constant<int, 2>;
 
     (void)fold_pass;
     // wave-level counters of the DEFER loop (scalar registers): every live lane casts once per trip
     unsigned w_casts = 0, w_bounces = 0, w_draws = 0;
+#ifdef RTM_EXP_TRIPS
+    unsigned w_trips64 = 0;
+#endif
     if constexpr (DEFER && REUSE) {
         // ---- primary-hit reuse (see REUSE above) ----
         // the primary hit of the lane's current sub-pixel: recomputed when the sub-pixel changes (once per S samples)
@@ -507,7 +564,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     fq_tail = (fq_tail + added) & (kFoldRing - 1);
                     fq_count += added;
                     const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;
-                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(std::false_type{});
+                    while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(ModeWhole{});
                 }
             }
             // ---- bounce: every lane holds a hit that passed the roulette (lanes out of samples: a dummy) ----
@@ -535,11 +592,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             rng.ctr = o.ctr;
             have_fresh_rays = true;
         }
-        while (fq_count > 0u) fold_pass(std::false_type{});
+        while (fq_count > 0u) fold_pass(ModeWhole{});
     }
     if constexpr (DEFER && !REUSE) {
-      auto trace = [&](auto small_tag) {
-        constexpr bool SMALL = SPLIT && decltype(small_tag)::value;
+      bool to_tail = false;  // STEAL: the main loop was left because a lane ran out of samples (wave-uniform)
+      auto trace = [&](auto mode_tag) {
+        constexpr bool SMALL = SPLIT && decltype(mode_tag)::value == 1;
         // Wave-uniform loop: fold_pass needs all 64 lanes whatever their own state, so a lane that has finished
         // its samples cannot leave.  It does not idle either: it keeps tracing (samples beyond its range, results
         // discarded — `live` gates the queue, the counters and nothing else), which costs nothing — the lanes are
@@ -549,6 +607,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             // lane masks as scalars (SGPR pairs straight from the compares): every count below is a popcount
             const unsigned long long m_live = __builtin_amdgcn_ballot_w64(n < n_end);
             if (m_live == 0ull) break;
+            if constexpr (STEAL && !SMALL) {
+                // a whole tile's first lane has run out of samples: the rest of the tile is the tail loop's
+                if (whole && m_live != ~0ull) {
+                    to_tail = true;
+                    return;
+                }
+            }
             const bool live = n < n_end;
             bool fifo_full = false;
             D3 term;
@@ -565,6 +630,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
             const unsigned n_cont = (unsigned)__builtin_popcountll(m_cont);
             w_casts += (unsigned)__builtin_popcountll(m_live);
+#ifdef RTM_EXP_TRIPS
+            w_trips64 += 64u;
+#endif
             w_draws += (unsigned)__builtin_popcountll(m_drew) + 2u * n_cont;
             w_bounces += n_cont;
             if (!cont) {
@@ -638,16 +706,155 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 fq_tail = (fq_tail + added) & (kFoldRing - 1);
                 fq_count += added;
                 const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;  // a lane's FIFO holds 8 positions
-                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(small_tag);
+                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(mode_tag);
             }
         }
-        while (fq_count > 0u) fold_pass(small_tag);
+        while (fq_count > 0u) fold_pass(mode_tag);
       };
       if constexpr (SPLIT) {
-          if (n_first != 0u) trace(std::true_type{});  // (a small wave's first sample is never 0: wave 0 keeps at least one share)
-          else trace(std::false_type{});
+          if (n_first != 0u) trace(ModeSmall{});  // (a small wave's first sample is never 0: wave 0 keeps at least one share)
+          else trace(ModeWhole{});
       } else {
-          trace(std::false_type{});
+          trace(ModeWhole{});
+      }
+      if constexpr (STEAL) {
+       if (whole) {
+        unsigned end_own = valid ? P.total_samples : 0u;  // one past the last sample this lane's pixel accumulated itself
+        if (to_tail) {
+          // ---- the tail loop of a whole tile (see STEAL above) ----
+          unsigned* st_next = reinterpret_cast<unsigned*>(fq_pend + 64);  // per pixel: the next own sample its lane will START
+          unsigned* st_end = st_next + 64;                               // per pixel: one past its last OWN sample
+          const unsigned total = P.total_samples;
+          bool busy = n < n_end;                                         // this lane has a path in flight ...
+          unsigned cur = ((unsigned)lane << 16) | (busy ? n : 0u);       // ... of (pixel lane, sample)
+          unsigned own_next = busy ? n + 1u : total;
+          st_next[lane] = own_next;
+          st_end[lane] = valid ? total : 0u;
+          unsigned claimed = 0u;                                         // samples taken from other pixels so far (wave-uniform)
+          const unsigned cap = P.steal_rows * 64u;
+          const unsigned floor_s = total > P.steal_depth ? total - P.steal_depth : 0u;
+          const unsigned tile_x8 = (blockIdx.x % (unsigned)P.tiles_x) * 8u, tile_y = blockIdx.x / (unsigned)P.tiles_x;
+          for (;;) {
+            const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(busy);
+            if (m_busy == 0ull) break;
+            bool fifo_full = false;
+            D3 term;
+            int hit_id;
+            const int depth_before = depth;
+            PathCounters unused = {0, 0, 0};
+            const bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig, &hit_id);
+            const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_busy;
+            unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_busy;
+            if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
+            const unsigned n_cont = (unsigned)__builtin_popcountll(m_cont);
+            w_casts += (unsigned)__builtin_popcountll(m_busy);
+            w_draws += (unsigned)__builtin_popcountll(m_drew) + 2u * n_cont;
+            w_bounces += n_cont;
+#ifdef RTM_EXP_TRIPS
+            w_trips64 += 64u;
+#endif
+            const bool ended = busy && !cont;
+            const bool need = !busy || !cont;  // this lane wants a new sample
+            if (ended) {
+                const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
+                const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
+                const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
+                const bool own = (cur >> 16) == (unsigned)lane;
+                fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, own ? 0u : (0x80000000u | cur)};
+                if (own) {  // the owner picks its term up again, in the order its paths ended
+                    const unsigned pend = (fq_pend[lane] & 0xFFu) + 1u;
+                    fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
+                    fq_pend[lane] = pend;
+                    fifo_full = pend >= 8u;
+                }
+            }
+            const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));
+            // (1) the lane's own next sample, if its pixel still has one that nobody took
+            bool got = false;
+            if (need && own_next < st_end[lane]) {
+                cur = ((unsigned)lane << 16) | own_next;
+                ++own_next;
+                st_next[lane] = own_next;
+                got = true;
+                if (--left_in_sub == 0) {
+                    left_in_sub = P.S;
+                    const int sub = (int)((cur & 0xFFFFu) / (unsigned)P.S);
+                    int px, py;
+                    pixel_xy(px, py);
+                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                    park[3 * 64 + lane] = pdir.x;
+                    park[4 * 64 + lane] = pdir.y;
+                    park[5 * 64 + lane] = pdir.z;
+                }
+                dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
+                rng = rng_open(pkey, cur & 0xFFFFu);
+            }
+            // (2) lanes left without one take the LAST unstarted samples of the pixel that has most to give: what it has
+            // not started, but one, and not below the depth the finalize kernel's index covers
+            const unsigned long long m_want = __builtin_amdgcn_ballot_w64(need && !got);
+            if (m_want != 0ull && claimed < cap) {
+                const unsigned e_l = st_end[lane], n_l = st_next[lane];
+                unsigned give = e_l > n_l + 1u ? e_l - n_l - 1u : 0u;
+                const unsigned above = e_l > floor_s ? e_l - floor_s : 0u;
+                give = give < above ? give : above;
+                give = give < 255u ? give : 255u;
+                unsigned long long cand = ~0ull;  // bitwise search for the largest `give`, lowest lane on ties
+#pragma unroll
+                for (int b = 7; b >= 0; --b) {
+                    const unsigned long long mb = __builtin_amdgcn_ballot_w64(((give >> b) & 1u) != 0u) & cand;
+                    cand = mb != 0ull ? mb : cand;
+                }
+                const int v = (int)__builtin_ctzll(cand);
+                const unsigned give_v = (unsigned)__builtin_amdgcn_readlane((int)give, v);
+                unsigned take = (unsigned)__builtin_popcountll(m_want);
+                take = take < give_v ? take : give_v;
+                take = take < cap - claimed ? take : cap - claimed;
+                if (take != 0u) {
+                    const unsigned e_v = (unsigned)__builtin_amdgcn_readlane((int)e_l, v);
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_want, 0u));
+                    if (need && !got && rank < take) {
+                        const unsigned s_st = e_v - 1u - rank;
+                        cur = ((unsigned)v << 16) | s_st;
+                        got = true;
+                        // pixel v of this tile, sample s_st: its primary ray and RNG stream from scratch (wave-uniform pixel)
+                        const int px = (int)tile_x8 + (v & 7), py = band_row(P, (int)tile_y, v >> 3);
+                        const RngPixelKey vkey = rng_pixel_key(P.seed_mult, (uint32_t)py * (uint32_t)P.W + (uint32_t)px);
+                        // s_st / S and sub / SS by multiplication (exact for operands below 2^16; a divisor of 1 has no magic)
+                        const unsigned sub = P.S == 1 ? s_st : __umulhi(s_st, P.magic_S);
+                        const unsigned sxm1 = P.SS == 1 ? sub : __umulhi(sub, P.magic_SS);
+                        dir = primary_dir_lds(P, cam, px, py, (int)sxm1 + 1, (int)(sub - sxm1 * (unsigned)P.SS) + 1);
+                        rng = rng_open(vkey, s_st);
+                    }
+                    if (lane == v) st_end[lane] = e_v - take;
+                    claimed += take;
+                }
+            }
+            if (need) {
+                busy = got;
+                org = P.cam_org;
+                depth = 0;
+                recq = packed8_empty(P.scene.n);
+            }
+            if (added != 0u) {
+                fq_tail = (fq_tail + added) & (kFoldRing - 1);
+                fq_count += added;
+                const bool force = __builtin_amdgcn_ballot_w64(fifo_full) != 0;
+                while (fq_count >= 64u || (force && fq_count > 0u)) fold_pass(ModeTail{});
+            }
+          }
+          while (fq_count > 0u) fold_pass(ModeTail{});
+          end_own = st_end[lane];
+        }
+        // the tile's block: accumulators, every pixel's own-sample end, the number of stolen terms
+        unsigned char* blk = P.steal_ws + (size_t)blockIdx.x * steal_tile_bytes(P.steal_rows);
+        double* part = reinterpret_cast<double*>(blk + kStealHdrBytes) + lane;
+        part[0] = park[0 * 64 + lane];
+        part[64] = park[1 * 64 + lane];
+        part[128] = park[2 * 64 + lane];
+        reinterpret_cast<unsigned short*>(blk + 128)[lane] = (unsigned short)end_own;
+        if (lane == 0) reinterpret_cast<unsigned*>(blk)[0] = stolen_out;
+       }
       }
     }
     unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
@@ -733,7 +940,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     }
 
     if constexpr (PARK) acc = d3(park[0 * 64 + lane], park[1 * 64 + lane], park[2 * 64 + lane]);
-    if (whole) {
+    if (STEAL && whole) {
+        // steal_finalize_kernel stores the pixel (the tail loop has left the tile's block in P.steal_ws)
+    } else if (whole) {
         int px, py;
         pixel_xy(px, py);
         store_pixel(P, (px < P.W) && (py < P.row_end), px, py, acc);
@@ -750,7 +959,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             if (lane == 0) {
                 atomicAdd(P.counters + 0, (unsigned long long)w_casts);
                 atomicAdd(P.counters + 1, (unsigned long long)w_bounces);
+#ifdef RTM_EXP_TRIPS
+                atomicAdd(P.counters + 2, (unsigned long long)w_trips64);  // EXPERIMENT: "draws" = 64 x trips of the wave
+#else
                 atomicAdd(P.counters + 2, (unsigned long long)w_draws);
+#endif
             }
         } else {
             wave_add_counter(P.counters + 0, pc.casts);
@@ -801,6 +1014,50 @@ __global__ __launch_bounds__(256) void split_finalize_kernel(const RenderParams 
     if (chan < 3) slot[chan * 64 + lane] = acc;
     __syncthreads();
     if (chan == 0) store_pixel(P, valid, px, py, d3(slot[lane], slot[64 + lane], slot[128 + lane]));
+}
+
+// Second half of a STEAL render (whole tiles): pixel = ((partial + term[end]) + term[end + 1]) + ... — the accumulation
+// order of src/Renderer.cpp:241-242 — where `partial` holds the samples [0, end) the pixel's own lane traced and the terms
+// of [end, total) were traced by other lanes of the tile and lie, in fold order and tagged (pixel lane, sample), in the
+// tile's rows.  One wave per tile: an index of row positions by (sample, pixel) in LDS, then every lane walks its pixel's
+// stolen samples in order.  LDS: steal_depth x 64 two-byte entries.
+__global__ __launch_bounds__(64) void steal_finalize_kernel(const RenderParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned short* idx = reinterpret_cast<unsigned short*>(lds_raw);  // [sample - floor][pixel lane] -> position in the rows
+    const int lane = threadIdx.x;
+    const unsigned tile = blockIdx.x;
+    const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    const int px = tx * 8 + (lane & 7), py = band_row(P, ty, lane >> 3);
+    const bool valid = (px < P.W) && (py < P.row_end);
+    const unsigned char* blk = P.steal_ws + (size_t)tile * steal_tile_bytes(P.steal_rows);
+    unsigned n_terms = reinterpret_cast<const unsigned*>(blk)[0];
+    unsigned end_own = reinterpret_cast<const unsigned short*>(blk + 128)[lane];
+    // (never out of range when the render kernel wrote the block; a stale or foreign block must not turn into a fault)
+    n_terms = n_terms <= P.steal_rows * 64u ? n_terms : 0u;
+    const unsigned floor_chk = P.total_samples > P.steal_depth ? P.total_samples - P.steal_depth : 0u;
+    end_own = (n_terms != 0u && end_own >= floor_chk && end_own <= P.total_samples) ? end_own : P.total_samples;
+    const double* part = reinterpret_cast<const double*>(blk + kStealHdrBytes) + lane;
+    D3 acc = d3(part[0], part[64], part[128]);
+    if (n_terms != 0u) {  // wave-uniform
+        const unsigned total = P.total_samples;
+        const unsigned floor_s = total > P.steal_depth ? total - P.steal_depth : 0u;
+        const unsigned char* rows = blk + kStealHdrBytes + 3 * 64 * sizeof(double);
+        for (unsigned e = (unsigned)lane; e < n_terms; e += 64u) {
+            const unsigned tag = reinterpret_cast<const unsigned*>(rows + (size_t)(e >> 6) * kStealRowBytes + 3 * 64 * sizeof(double))[e & 63u];
+            const unsigned ts = tag & 0xFFFFu, tv = (tag >> 16) & 63u;
+            if (ts >= floor_s && ts < total) idx[(ts - floor_s) * 64u + tv] = (unsigned short)e;
+        }
+        __syncthreads();
+        if (valid) {
+            for (unsigned s = end_own; s < total; ++s) {
+                unsigned e = idx[(s - floor_s) * 64u + (unsigned)lane];
+                e = e < n_terms ? e : 0u;
+                const double* v = reinterpret_cast<const double*>(rows + (size_t)(e >> 6) * kStealRowBytes) + (e & 63u);
+                acc = acc + d3(v[0], v[64], v[128]);
+            }
+        }
+    }
+    store_pixel(P, valid, px, py, acc);
 }
 
 }  // namespace rtm
