@@ -30,6 +30,13 @@ int rtm_debug_wf_nearest(int kind, const rtm_sphere* spheres, size_t n, const do
  * *tflops counts an FMA as 2 flops.  bench.py puts it beside the datasheet figure ("verify by
  * microbenchmark"); profiles/ubench/fp64_peak.hip is the stand-alone form with the per-instruction price list. */
 int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms);
+/* The uniform-grid nearest-hit search of variant 17 (csrc/rtm_path.h: nearest_hit_grid) on caller-supplied rays
+ * (org, dir: n_rays x 3 doubles, HOST): hit object (-1: none) and distance per ray as the reference loop
+ * (src/Renderer.cpp:58-73) finds them — kind 1 of rtm_debug_wf_nearest is that loop — plus, where the pointers are not
+ * NULL, the sphere tests and cell steps each ray took and info[6] = {cells, cell-list entries, spheres tested by every
+ * ray, dim x, dim y, dim z}.  RTM_ERR_UNSUPPORTED when the scene gets no grid. */
+int rtm_debug_grid_nearest(const rtm_sphere* spheres, size_t n, const double* org, const double* dir, size_t n_rays,
+                           int32_t* out_id, double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */
 int rtm_debug_component_bench(int which, const rtm_sphere* spheres, size_t n, int reps, int blocks, int lds_pad,
                               double* cycles_per_rep);

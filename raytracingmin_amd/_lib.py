@@ -119,6 +119,8 @@ DEBUG_SIGNATURES = {
     "rtm_debug_fp64_peak": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rtm_debug_wf_nearest": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_void_p]),
+    "rtm_debug_grid_nearest": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_double)]),
 }

@@ -117,6 +117,10 @@ int rtm_debug_wf_nearest(int kind, const rtm_sphere* sp, size_t n, const double*
     RTM_GUARD(rtm::wf_nearest_probe(kind, sp, n, org, dir, n_rays, out_id, out_t))
 }
 int rtm_debug_selfcheck(int kind, unsigned long long* mismatches) { RTM_GUARD(rtm::selfcheck(kind, mismatches)) }
+int rtm_debug_grid_nearest(const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays,
+                           int32_t* out_id, double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info) {
+    RTM_GUARD(rtm::grid_nearest_probe(sp, n, org, dir, n_rays, out_id, out_t, out_tests, out_steps, info))
+}
 int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms) {
     RTM_GUARD(rtm::fp64_peak(waves_per_simd, min_ms, tflops, kernel_ms))
 }

@@ -48,6 +48,8 @@ double rng_u01_host(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t ind
 int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blocks, int lds_pad,
                     double* cycles_per_rep);
 int selfcheck(int kind, unsigned long long* mismatches);
+int grid_nearest_probe(const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays, int32_t* out_id,
+                       double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info);
 int fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms);
 int math_probe(int op, const double* a, const double* b, size_t n, double* out);
 

@@ -241,6 +241,9 @@ struct rtm_scene {
     int device = 0;
     size_t n = 0;
     rtm::DevMem geom, mat, aux, plane;  // plane: 16 doubles per object, only for scenes that hold planes
+    rtm::DevMem grid;                   // large all-sphere scenes: GridHeader + cell offsets + cell lists + big list
+    size_t grid_cells = 0, grid_refs = 0, grid_big = 0;
+    rtm::GridHeader grid_hdr;           // host copy (grid_for: is the camera within the pads' reach?)
     bool has_planes = false;
     uint64_t content_hash = 0;            // cache entries only ...
     std::vector<unsigned char> content;   // ... and the bytes the hash was taken of (compared on a hash hit)
@@ -275,9 +278,10 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
     return RTM_OK;
 }
 static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n,
-                            const double* plane = nullptr) {
+                            const double* plane = nullptr, const void* grid = nullptr) {
     SceneView v{(const double4*)geom, mat, (int)n};
     v.plane = plane;
+    v.grid = static_cast<const GridHeader*>(grid);
     if (aux) {
         const size_t n_pad = (n + 7) & ~(size_t)7;
         v.bounds = aux;
@@ -288,9 +292,207 @@ static SceneView scene_view(const double* geom, const double* mat, const double*
     return v;
 }
 
+// ---- uniform grid of a large scene (rtm_path.h: GridHeader, nearest_hit_grid — where the pads are derived) ----------
+// Built on the host from the flattened geometry rows (cx, cy, cz, float r*r) when a scene OBJECT is created: a few
+// milliseconds for 100 000 spheres, once per scene.  ~kGridCellsPerSphere cells per sphere; a sphere whose padded box
+// covers more than kGridBigCells cells goes to the list every ray tests.  No grid (the other kernels serve the scene)
+// for fewer than kGridMinSpheres spheres, non-finite geometry, more than kGridMaxBig big spheres or planes.
+#ifndef RTM_GRID_WPE
+#define RTM_GRID_WPE 4
+#endif
+constexpr int kGridWavesPerSimd = RTM_GRID_WPE;  // launch bound of the grid kernel (profiles/r3/grid_tune.txt)
+constexpr size_t kGridMinSpheres = 257;  // (ids beyond a byte: the grid kernel is instantiated for u32 records only)
+constexpr int kGridBigCells = 125, kGridMaxBig = 1024, kGridMaxDim = 1024;
+constexpr double kGridDdTol = 4e-7;  // |dir.dir - 1| the pads cover: twice what the reference's float-sqrt Normalize leaves (1.8e-7)
+static double grid_cells_per_sphere() {
+    static const double v = [] {
+        const char* e = std::getenv("RTM_DEBUG_GRID_CELLS");  // tuning knob: cells per sphere; 0 = build no grid
+        return e ? std::strtod(e, nullptr) : 2.0;
+    }();
+    return v;
+}
+struct GridBuild {
+    GridHeader hdr;
+    std::vector<unsigned> cell_start, items;
+    std::vector<int> big;
+    size_t refs = 0;  // entries of `items` that are real (items holds one dummy when there is none)
+};
+static bool n_refs_valid(const GridBuild& B) { return B.refs != 0; }
+static bool make_grid(const double* g, size_t n, GridBuild& out) {
+    const double lambda = grid_cells_per_sphere();
+    if (n < kGridMinSpheres || n >= (1u << 29) || !(lambda > 0.0)) return false;
+    std::vector<double> R(n), pad(n);
+    std::vector<char> is_big(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const double* r = g + i * 4;
+        if (!(std::isfinite(r[0]) && std::isfinite(r[1]) && std::isfinite(r[2]) && std::isfinite(r[3]) && r[3] >= 0.0)) return false;
+        unsigned long long wbits;
+        std::memcpy(&wbits, &r[3], sizeof wbits);
+        if (wbits & 0x1FFFFFFFull) return false;  // (never: r*r is a float widened to double — the records keep the index there)
+        R[i] = std::sqrt(r[3]);
+    }
+    double lo[3], hi[3], h = 0.0, t_ok = 0.0;
+    size_t n_small = n;
+    for (int round = 0; round < 4; ++round) {
+        // box of the small spheres (unpadded), cell edge from its volume, pads from its diagonal
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = HUGE_VAL;
+            hi[k] = -HUGE_VAL;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (is_big[i]) continue;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], g[i * 4 + k] - R[i]);
+                hi[k] = std::max(hi[k], g[i * 4 + k] + R[i]);
+            }
+        }
+        double ext[3], diag2 = 0.0, vol = 1.0, longest = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            ext[k] = hi[k] - lo[k];
+            diag2 += ext[k] * ext[k];
+            longest = std::max(longest, ext[k]);
+        }
+        if (!(longest > 0.0) || !std::isfinite(diag2)) return false;
+        for (int k = 0; k < 3; ++k) vol *= std::max(ext[k], longest * 1e-3);  // (a flat scene still gets cells of a sane size)
+        h = std::cbrt(vol / (lambda * (double)n_small));
+        h = std::max(h, longest / (double)(kGridMaxDim - 2));
+        t_ok = 2.5 * std::sqrt(diag2);
+        size_t changed = 0;
+        n_small = 0;
+        for (size_t i = 0; i < n; ++i) {
+            // (rtm_path.h: a hit at parameter t lies sqrt(r^2 + t^2 (d.d - 1)) from the centre)
+            pad[i] = 0.05 * h + (std::sqrt(R[i] * R[i] + kGridDdTol * t_ok * t_ok) - R[i]) + 1e-6 * t_ok;
+            const double side = 2.0 * (R[i] + pad[i]) / h + 1.0;
+            const char b = !(side * side * side <= (double)kGridBigCells);
+            changed += b != is_big[i];
+            is_big[i] = b;
+            n_small += !b;
+        }
+        if (n_small < kGridMinSpheres) return false;
+        if (!changed && round > 0) break;
+    }
+    out.big.clear();
+    for (size_t i = 0; i < n; ++i)
+        if (is_big[i]) out.big.push_back((int)i);
+    if (out.big.size() > (size_t)kGridMaxBig) return false;
+    // the grid's box: the small spheres' padded boxes
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = HUGE_VAL;
+        hi[k] = -HUGE_VAL;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (is_big[i]) continue;
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], g[i * 4 + k] - R[i] - pad[i]);
+            hi[k] = std::max(hi[k], g[i * 4 + k] + R[i] + pad[i]);
+        }
+    }
+    GridHeader& H = out.hdr;
+    std::memset(&H, 0, sizeof H);
+    size_t cells = 1;
+    for (int k = 0; k < 3; ++k) {
+        lo[k] -= 0.01 * h;
+        int d = (int)std::ceil((hi[k] + 0.01 * h - lo[k]) / h);
+        d = d < 1 ? 1 : d;
+        if (d > kGridMaxDim) return false;
+        H.lo[k] = lo[k];
+        H.hi[k] = lo[k] + (double)d * h;
+        H.dim[k] = d;
+        cells *= (size_t)d;
+    }
+    if (cells > 64 * n + 4096) return false;  // (cannot happen with cells of the volume's size; a guard for the host's memory)
+    H.h = h;
+    H.inv_h = 1.0 / h;
+    H.t_ok = t_ok;
+    double half2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        H.cb[k] = 0.5 * (H.lo[k] + H.hi[k]);
+        half2 += 0.25 * (H.hi[k] - H.lo[k]) * (H.hi[k] - H.lo[k]);
+    }
+    const double reach = t_ok / 1.001 - std::sqrt(half2);  // (t_ok = 2.5 diagonals of the unpadded box: about two of them)
+    if (!(reach > 0.0)) return false;
+    H.reach2 = reach * reach;
+    H.dd_tol = kGridDdTol;
+    H.n_big = (int)out.big.size();
+    // counting sort of (cell, sphere) pairs; spheres are visited in index order, so every cell's list ascends
+    auto cell_range = [&](size_t i, int k, int& a, int& b) {
+        const double c = g[i * 4 + k], e = R[i] + pad[i];
+        a = (int)std::floor((c - e - H.lo[k]) / h);
+        b = (int)std::floor((c + e - H.lo[k]) / h);
+        a = a < 0 ? 0 : a;
+        b = b >= H.dim[k] ? H.dim[k] - 1 : b;
+    };
+    out.cell_start.assign(cells + 1, 0u);
+    size_t refs = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t i = 0; i < n; ++i) {
+            if (is_big[i]) continue;
+            int a[3], b[3];
+            for (int k = 0; k < 3; ++k) cell_range(i, k, a[k], b[k]);
+            for (int z = a[2]; z <= b[2]; ++z)
+                for (int y = a[1]; y <= b[1]; ++y)
+                    for (int x = a[0]; x <= b[0]; ++x) {
+                        const size_t c = ((size_t)z * H.dim[1] + y) * H.dim[0] + x;
+                        if (pass == 0) {
+                            ++out.cell_start[c + 1];
+                            ++refs;
+                        } else {
+                            out.items[out.cell_start[c]++] = (unsigned)i;
+                        }
+                    }
+        }
+        if (pass == 0) {
+            if (refs > 0xFFFFFF00ull) return false;
+            for (size_t c = 0; c < cells; ++c) out.cell_start[c + 1] += out.cell_start[c];
+            out.items.assign(refs ? refs : 1, 0u);
+            out.refs = refs;
+        } else {  // the fill advanced every start to its end: shift back
+            for (size_t c = cells; c > 0; --c) out.cell_start[c] = out.cell_start[c - 1];
+            out.cell_start[0] = 0u;
+        }
+    }
+    return true;
+}
+// Build + upload; a scene that gets no grid keeps sc.grid empty (not an error).  `hg`: the host copy of the geometry rows.
+static int build_scene_grid(rtm_scene& sc, const double* hg, size_t n, int device) {
+    GridBuild B;
+    if (sc.has_planes || !make_grid(hg, n, B)) return RTM_OK;
+    const size_t off_cs = (sizeof(GridHeader) + 255) & ~(size_t)255;
+    const size_t off_items = off_cs + ((B.cell_start.size() * sizeof(unsigned) + 255) & ~(size_t)255);
+    const size_t off_big = off_items + ((B.items.size() * 4 * sizeof(double) + 255) & ~(size_t)255);
+    // the cell lists as self-contained records: the geometry row with the sphere's index in r*r's 29 zero mantissa bits
+    std::vector<double> recs(B.items.size() * 4);
+    for (size_t k = 0; k < B.items.size(); ++k) {
+        const unsigned i = n_refs_valid(B) ? B.items[k] : 0u;
+        std::memcpy(&recs[k * 4], hg + (size_t)i * 4, 4 * sizeof(double));
+        unsigned long long wbits;
+        std::memcpy(&wbits, &recs[k * 4 + 3], sizeof wbits);
+        wbits |= (unsigned long long)i;
+        std::memcpy(&recs[k * 4 + 3], &wbits, sizeof wbits);
+    }
+    const size_t bytes = off_big + (B.big.size() + 1) * sizeof(int);
+    const int rc = sc.grid.alloc_pooled(bytes, device);
+    if (rc != RTM_OK) return rc;
+    unsigned char* base = sc.grid.as<unsigned char>();
+    B.hdr.cell_start = reinterpret_cast<const unsigned*>(base + off_cs);
+    B.hdr.recs = reinterpret_cast<const double4*>(base + off_items);
+    B.hdr.n_recs = (unsigned)B.items.size();
+    B.hdr.big = reinterpret_cast<const int*>(base + off_big);
+    RTM_HIP_CHECK(hipMemcpy(base, &B.hdr, sizeof B.hdr, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(base + off_cs, B.cell_start.data(), B.cell_start.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(base + off_items, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (!B.big.empty())
+        RTM_HIP_CHECK(hipMemcpy(base + off_big, B.big.data(), B.big.size() * sizeof(int), hipMemcpyHostToDevice));
+    sc.grid_hdr = B.hdr;
+    sc.grid_cells = B.cell_start.size() - 1;
+    sc.grid_refs = B.items.size();
+    sc.grid_big = B.big.size();
+    return RTM_OK;
+}
+
 // Flatten + upload a HOST sphere array; returns when the tables are resident (the caller's array and
 // the staging vectors may go away).  Runs on the device's null stream.
-static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int device) {
+static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int device, bool want_grid = true) {
     RTM_HIP_CHECK(hipSetDevice(device));
     sc.device = device;
     sc.n = n;
@@ -305,7 +507,7 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return RTM_OK;
+    return want_grid ? build_scene_grid(sc, hg.data(), n, device) : RTM_OK;
 }
 // The same from a DEVICE sphere array.
 static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n, int device) {
@@ -321,7 +523,10 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return RTM_OK;
+    if (n < kGridMinSpheres) return RTM_OK;
+    std::vector<double> hg(n * 4);  // the grid is built on the host: the geometry rows come back once
+    RTM_HIP_CHECK(hipMemcpy(hg.data(), sc.geom.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return build_scene_grid(sc, hg.data(), n, device);
 }
 
 int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_scene** out) {
@@ -378,7 +583,7 @@ int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene
         }
     }
     std::unique_ptr<rtm_scene> sc(new rtm_scene);
-    int rc = scene_build_host(*sc, view.data(), n, device);
+    int rc = scene_build_host(*sc, view.data(), n, device, !any_plane);
     if (rc != RTM_OK) return rc;
     if (any_plane) {
         // a plane's geometry row is (position, -1): the negative "r*r" marks it for the per-object loop
@@ -675,11 +880,13 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       ("LABELLED-primary-hit-reuse (one nearest-hit search per sub-pixel for its S primary rays; "
                                        "not the reference's work per sample)"),
                                       ("LABELLED-fp32-fast (single precision, hardware sqrt/rsq/sin/cos, fused multiply-adds, "
-                                       "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)")};
+                                       "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)"),
+                                      ("fast-math-uniform-grid (large scenes held by an rtm_scene: the reference loop's nearest hit "
+                                       "through a uniform grid over the spheres, same image bit for bit)")};
 #undef RTM_RETIRED
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3, kVariantStamped = 7,
               kVariantSplit = 9, kVariantWavefrontRejectF32 = 12, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15,
-              kVariantFp32 = 16;
+              kVariantFp32 = 16, kVariantGrid = 17;
 static bool variant_retired(int v) { return v == 4 || v == 5 || v == 6 || v == 8 || v == 10 || v == 11 || v == 13; }
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
@@ -868,6 +1075,9 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
         }
         case kVariantStamped:  // render_view: n <= kLdsTableMaxSpheres
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true, true>(P, grid, stream);
+            return;
+        case kVariantGrid:  // render_view: the scene has a grid (n >= 257)
+            launch_render_depth<MathFast, false, kUnrollGrid, uint32_t, kGridWavesPerSimd>(P, grid, stream);
             return;
         default:  // kVariantFastGlobal: the chunked kernel with global-memory tables, any n
             if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
@@ -1368,7 +1578,13 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     }
     if (variant == kVariantAuto)
         variant = n <= (size_t)kAutoLdsTableSpheres ? kVariantFastLds : n < 256 ? kVariantGlobalDefer :
-                  n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
+                  n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal :
+                  view.grid != nullptr ? kVariantGrid : kVariantWavefrontRejectF32;
+    if (variant == kVariantGrid && view.grid == nullptr) {
+        set_last_error("variant 17 (uniform grid) serves all-sphere scenes of 257 spheres or more held by an rtm_scene "
+                       "(rtm_scene_create*, rtm_render_rows*); this scene has no grid");
+        return RTM_ERR_UNSUPPORTED;
+    }
     else if (variant == kVariantSplit)
         variant = kVariantFastLds;
     if (view.plane != nullptr) {
@@ -1473,6 +1689,15 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         P.stamps = stamps.as<unsigned long long>();
     }
 
+    if (variant == kVariantGrid) {
+        static const bool xcd_off = [] {
+            const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
+            return e && e[0] == '0';
+        }();
+        P.xcd_on = xcd_off ? 0u : 1u;
+        P.xcd_q = grid / 8u;
+        P.xcd_rem = grid % 8u;
+    }
     EventPair ev;
     if (stats) {
         rc = ev.create();
@@ -1522,6 +1747,17 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     return RTM_OK;
 }
 
+// The scene's grid as this render may use it: always when variant 17 is asked for by name; for the automatic choice only
+// when the camera is within the reach the grid's pads were sized for (GridHeader::reach2 — a camera farther than about
+// two scene diagonals away would send every primary ray through the exhaustive loop instead).
+static const void* grid_for(const rtm_scene* sc, const rtm_settings* st, const rtm_options* opt) {
+    if (!sc->grid.p) return nullptr;
+    if (opt->variant == kVariantGrid) return sc->grid.p;
+    double d2 = 0.0;
+    for (int k = 0; k < 3; ++k) d2 += (st->camera.origin[k] - sc->grid_hdr.cb[k]) * (st->camera.origin[k] - sc->grid_hdr.cb[k]);
+    return (d2 <= sc->grid_hdr.reach2) ? sc->grid.p : nullptr;  // (NaN: no)
+}
+
 int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
                  uint8_t* out8, void* stream_v, rtm_stats* stats) {
     if (!scene) {
@@ -1538,7 +1774,7 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
     std::shared_lock<std::shared_mutex> gate(g_gate);
     reap_scenes(false);
     rc = render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                    scene->has_planes ? scene->plane.as<double>() : nullptr),
+                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt)),
                      scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
     note_scene_use(scene, (hipStream_t)stream_v);  // also after a failure: part of the work may have been queued
     return rc;
@@ -1556,8 +1792,8 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_scene(sp, n, opt->device, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n), n, opt,
-                         out64, out32, out8, stream, stats);
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt)),
+                         n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
         return rc;
     }
@@ -1892,6 +2128,56 @@ int wf_nearest_probe(int kind, const rtm_sphere* sp, size_t n, const double* org
     RTM_HIP_CHECK(hipDeviceSynchronize());
     RTM_HIP_CHECK(hipMemcpy(out_id, S.hit_id, N * 4, hipMemcpyDeviceToHost));
     RTM_HIP_CHECK(hipMemcpy(out_t, S.hit_t, N * 8, hipMemcpyDeviceToHost));
+    return RTM_OK;
+}
+
+// rtm_debug_grid_nearest: the grid search of variant 17 on the caller's rays (AoS org/dir, n_rays x 3), with the per-ray
+// counts of sphere tests and cell steps and the grid's size — tests/ compare it with kind 1 of rtm_debug_wf_nearest.
+int grid_nearest_probe(const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays, int32_t* out_id,
+                       double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info) {
+    if (!sp || !n || !org || !dir || !n_rays || !out_id || !out_t || n_rays > 0x7FFFFFFFull) return RTM_ERR_INVALID_ARGUMENT;
+    int device = 0;
+    RTM_HIP_CHECK(hipGetDevice(&device));
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, device);
+    if (rc != RTM_OK) return rc;
+    if (!ds.grid.p) {
+        set_last_error("this scene gets no grid (fewer than 257 gridded spheres, non-finite geometry, or too many spheres "
+                       "that span the scene)");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    if (info) {
+        GridHeader H;
+        RTM_HIP_CHECK(hipMemcpy(&H, ds.grid.p, sizeof H, hipMemcpyDeviceToHost));
+        info[0] = ds.grid_cells;
+        info[1] = ds.grid_refs;
+        info[2] = ds.grid_big;
+        info[3] = (uint64_t)H.dim[0];
+        info[4] = (uint64_t)H.dim[1];
+        info[5] = (uint64_t)H.dim[2];
+    }
+    const size_t N = n_rays;
+    DevMem d_org, d_dir, d_t, d_id, d_tests, d_steps;
+    if ((rc = d_org.alloc(N * 24)) != RTM_OK || (rc = d_dir.alloc(N * 24)) != RTM_OK || (rc = d_t.alloc(N * 8)) != RTM_OK ||
+        (rc = d_id.alloc(N * 4)) != RTM_OK || (rc = d_tests.alloc(N * 4)) != RTM_OK || (rc = d_steps.alloc(N * 4)) != RTM_OK)
+        return rc;
+    std::vector<double> soa(N * 3);
+    for (size_t i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * N + i] = org[i * 3 + k];
+    RTM_HIP_CHECK(hipMemcpy(d_org.p, soa.data(), N * 24, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * N + i] = dir[i * 3 + k];
+    RTM_HIP_CHECK(hipMemcpy(d_dir.p, soa.data(), N * 24, hipMemcpyHostToDevice));
+    const SceneView sv = scene_view(ds.geom.as<double>(), ds.mat.as<double>(), nullptr, n, nullptr, ds.grid.p);
+    grid_probe_kernel<<<(unsigned)((N + 255) / 256), 256>>>(sv, d_org.as<double>(), d_dir.as<double>(), (unsigned)N,
+                                                            d_id.as<int>(), d_t.as<double>(), d_tests.as<unsigned>(),
+                                                            d_steps.as<unsigned>());
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipDeviceSynchronize());
+    RTM_HIP_CHECK(hipMemcpy(out_id, d_id.p, N * 4, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out_t, d_t.p, N * 8, hipMemcpyDeviceToHost));
+    if (out_tests) RTM_HIP_CHECK(hipMemcpy(out_tests, d_tests.p, N * 4, hipMemcpyDeviceToHost));
+    if (out_steps) RTM_HIP_CHECK(hipMemcpy(out_steps, d_steps.p, N * 4, hipMemcpyDeviceToHost));
     return RTM_OK;
 }
 

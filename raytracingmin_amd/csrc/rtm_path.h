@@ -455,6 +455,23 @@ __device__ __forceinline__ D3 normalize_i(MI& m, D3 a) {
 // Scene policies.  geom[i] = (cx, cy, cz, (double)(float)(r*r)); mat[i*8..] = colorKD.xyz,
 // emission.xyz, kd, pad (the fold reads the first six doubles of a row as three 16-byte loads).
 // ------------------------------------------------------------------------------------------------
+// Uniform grid over a large scene's spheres (rtm_kernels.hip: build_scene_grid; nearest_hit_grid below).  Device memory,
+// read through wave-uniform scalar loads.  A sphere is listed in every cell its box — centre +- (radius + pad_i) —
+// overlaps; the few spheres whose box would cover too many cells are in `big` instead and are tested by every ray.
+struct GridHeader {
+    double lo[3], hi[3];  // the grid's box: hi = lo + dim * h
+    double h, inv_h;      // cell edge
+    double cb[3], reach2; // a ray whose origin is farther than sqrt(reach2) from the box's centre cb, ...
+    double dd_tol;        // ... or whose |dir.dir - 1| is larger, takes the exhaustive loop (the pads do not cover it)
+    double t_ok;          // the largest hit parameter the pads were sized for (host side; reach2 follows from it)
+    int dim[3];
+    int n_big;
+    unsigned n_recs, pad_;
+    const unsigned* cell_start;  // dim[0]*dim[1]*dim[2] + 1 offsets into `recs`
+    const double4* recs;         // a cell's spheres, self-contained: (cx, cy, cz, r*r | index), ascending index within a cell
+    const int* big;              // n_big sphere indices, ascending
+};
+
 struct SceneView {
     const double4* __restrict__ geom;
     const double* __restrict__ mat;
@@ -472,6 +489,8 @@ struct SceneView {
     // right, upv, right.right, upv.upv, 0, 0 — valid where geom[i].w < 0 (a sphere's r*r is never negative); null
     // for all-sphere scenes.  Served by the per-object loop only (variant 1).
     const double* __restrict__ plane = nullptr;
+    // large all-sphere scenes held by an rtm_scene: the uniform grid of the grid kernel (variant 17), else null
+    const GridHeader* __restrict__ grid = nullptr;
 };
 
 // png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line
@@ -824,8 +843,217 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 
 // src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
 // UNROLL == 1: the literal loop.  UNROLL > 1: batches of UNROLL spheres (sphere_batch).
+// ------------------------------------------------------------------------------------------------
+// The nearest-hit loop of src/Renderer.cpp:58-73 for LARGE scenes, through a uniform grid: the same (hit object, dis)
+// as the loop over all objects, from a fraction of its Intersect calls.
+//
+// Why it is the same.  The loop's result is the lexicographic minimum of (t, index) over the spheres whose Intersect
+// reports a hit with t > 0 (strict `t < dis` in index order = the lowest index among equal t), so any order of testing
+// gives it as long as ties are broken by index and every sphere that could win IS tested.  Intersect's t is a root of
+// t^2 - 2bt + (|c - o|^2 - r^2), so the point o + t d lies at distance sqrt(r^2 + t^2 (d.d - 1)) of the centre:
+// on the sphere but for the direction's float-normalised length (|d.d - 1| <= 1.8e-7, src/Ray.h:67-72) and rounding.
+// (The reference's loop in effect sees every sphere inflated to that radius: a far, tiny sphere is "hit" by rays that
+// pass it at up to sqrt(|d.d - 1|) t.)  Each sphere is listed in every cell within pad_i of its box,
+// pad_i = 0.05 h + (sqrt(r_i^2 + dd_tol t_ok^2) - r_i) + 1e-6 t_ok, which covers that excess for every t <= t_ok and
+// |d.d - 1| <= dd_tol = 4e-7, the rounding of t itself (<= 1e-7 t for a grazing hit), the DDA's own rounding (1e-12)
+// by ten orders of magnitude, and a sphere hit in a cell the DDA cuts at a corner (it is listed in the neighbours too).
+// So when the walk stops at a cell whose exit parameter is >= dis, every sphere with a hit before that exit has been
+// tested, and a ray that misses the grid's box (the padded boxes' union) hits nothing.  A hit's parameter is at most
+// |c - o| |d| + sqrt(|c - o|^2 (d.d - 1) + r^2) <= 1.001 x the distance from o to the farthest point of the box, so
+// t <= t_ok holds for every origin within reach = t_ok / 1.001 - half the box's diagonal of the box's centre.  Rays
+// outside those bounds (a far-away origin; a direction that is not unit length: the reference's arithmetic then "hits"
+// spheres the geometric ray passes at a distance) take the exhaustive loop; rays with a non-finite component hit
+// nothing in the reference loop either (every t is NaN or infinite).
+// Spheres in `big` (padded box over too many cells) are tested for every ray.
+constexpr int kUnrollGrid = 1000;
+#ifndef RTM_GRID_K
+#define RTM_GRID_K 4
+#endif
+constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_tune.txt)
+#ifndef RTM_GRID_SHADE_AT
+#define RTM_GRID_SHADE_AT 4
+#endif
+constexpr int kGridShadeAt8 = RTM_GRID_SHADE_AT;  // the render loop shades when this many eighths of a wave's lanes have finished their walks
+
+// One ray's walk through the grid, as per-lane state that can be advanced a trip at a time: the render kernel's lanes
+// walk independently and are shaded in groups (rtm_render_kernel.h), the probe and the plain nearest_hit run it to the end.
+template <class M, class Scene, bool COUNT = false>
+struct GridWalk {
+    double dis;  // the nearest accepted hit so far (DBL_MAX: none) and its object
+    int best;
+    double tmx, tmy, tmz;  // parameter at which the ray leaves the NEXT cell's predecessor planes (Amanatides & Woo's tMax)
+    double tdx, tdy, tdz;  // parameter per cell along each axis, signed like the direction (inf: never)
+    double t_exit;         // parameter at which the ray leaves the current cell
+    int ix, iy, iz;        // the NEXT cell
+    unsigned j, jend, nj, nje;  // records left in the current cell; the next cell's list
+    bool next_ok;               // the next cell is inside the grid
+    unsigned tests, steps;      // (COUNT: the probe's diagnostics, rtm_debug_grid_nearest)
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) GridHeader* HdrPtr;
+    static __device__ __forceinline__ HdrPtr header(const Scene& sc) { return (HdrPtr)(unsigned long long)sc.v.grid; }
+#else
+    typedef const GridHeader* HdrPtr;
+    static HdrPtr header(const Scene& sc) { return sc.v.grid; }
+#endif
+
+    __device__ __forceinline__ void consider(const int i, const double4 g, const D3 org, const D3 dir) {
+        if constexpr (COUNT) ++tests;
+        const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
+        const double b = dot(p_o, dir);                            // :199
+        const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200
+        if (D4 >= 0.0) {                                           // :202 (a NaN D4 ends in a NaN t: never accepted)
+            const double sq = M::sqrt64(D4);
+            const double t1 = b - sq, t2 = b + sq;
+            const double t = (t1 > 0.001) ? t1 : t2;  // :212-223; accepted as in sphere_update, ties to the lower index
+            const bool accept = !(t < (double)1e-5f) && (t < dis || (t == dis && i < best));
+            dis = accept ? t : dis;
+            best = accept ? i : best;
+        }
+    }
+    // The step out of the current cell: the axis whose boundary comes first (a NaN among the three falls through to z:
+    // the walk still ends, each index moves one way only), the cell's exit parameter, and the next cell's offsets.
+    __device__ __forceinline__ void plan_next(HdrPtr G) {
+        const int nx = G->dim[0], ny = G->dim[1], nz = G->dim[2];
+        const bool ax = tmx <= tmy && tmx <= tmz, ay = !ax && tmy <= tmz, az = !ax && !ay;
+        t_exit = ax ? tmx : (ay ? tmy : tmz);
+        ix += ax ? (tdx < 0.0 ? -1 : 1) : 0;
+        iy += ay ? (tdy < 0.0 ? -1 : 1) : 0;
+        iz += az ? (tdz < 0.0 ? -1 : 1) : 0;
+        tmx += ax ? fabs(tdx) : 0.0;
+        tmy += ay ? fabs(tdy) : 0.0;
+        tmz += az ? fabs(tdz) : 0.0;
+        next_ok = (unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz;
+        const unsigned cell = next_ok ? ((unsigned)iz * ny + iy) * nx + ix : 0u;
+        const unsigned* cs = G->cell_start;
+        nj = cs[cell];
+        nje = cs[cell + 1];
+    }
+    // Start the walk of (org, dir): the big list, the box, the guards.  Returns whether there is a walk to advance
+    // (false: dis / best are final — a miss of the box, a non-finite ray, or the exhaustive loop has run).
+    __device__ __forceinline__ bool begin(const Scene& sc, const D3 org, const D3 dir) {
+        HdrPtr G = header(sc);
+        best = -1;
+        dis = DBL_MAX;
+        if constexpr (COUNT) tests = steps = 0;
+        const int n_big = G->n_big;
+        const int* big = G->big;
+        for (int k = 0; k < n_big; ++k) {
+            const int i = __builtin_amdgcn_readfirstlane(big[k]);
+            consider(i, sc.geom_uniform(i), org, dir);
+        }
+        bool live = __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z) &&
+                    __builtin_isfinite(dir.x) && __builtin_isfinite(dir.y) && __builtin_isfinite(dir.z);
+        // the ray's parameter interval inside the grid's box
+        double t0 = 0.0, t_out = DBL_MAX;
+        const double inf = __builtin_huge_val();
+        auto slab = [&](const double o, const double d, const double lo, const double hi, double& inv) {
+            const bool flat = d == 0.0;
+            inv = 1.0 / d;
+            const double ta = (lo - o) * inv, tb = (hi - o) * inv;
+            const double tn = flat ? ((o >= lo && o <= hi) ? -inf : inf) : (ta < tb ? ta : tb);
+            const double tf = flat ? inf : (ta < tb ? tb : ta);
+            t0 = tn > t0 ? tn : t0;
+            t_out = tf < t_out ? tf : t_out;
+        };
+        const double lox = G->lo[0], loy = G->lo[1], loz = G->lo[2];
+        double invx, invy, invz;
+        slab(org.x, dir.x, lox, G->hi[0], invx);
+        slab(org.y, dir.y, loy, G->hi[1], invy);
+        slab(org.z, dir.z, loz, G->hi[2], invz);
+        const D3 oc = d3(org.x - G->cb[0], org.y - G->cb[1], org.z - G->cb[2]);
+        const bool exhaustive = live && !(dot(oc, oc) <= G->reach2 && fabs(dot(dir, dir) - 1.0) <= G->dd_tol);
+        live = live && (t0 <= t_out);
+        if (__builtin_amdgcn_ballot_w64(exhaustive) != 0) {  // (never, for a camera within two scene diagonals and unit directions)
+            const int n = sc.n();
+            for (int i = 0; i < n; ++i) {
+                const double4 g = sc.geom_uniform(i);
+                if (exhaustive) consider(i, g, org, dir);
+            }
+        }
+        live = live && !exhaustive;
+        // 3D-DDA over the cells from the entry point on (Amanatides & Woo).  The search is bound by memory latency as much
+        // as by arithmetic (a cell's list is a dependent load behind the cell's offsets), so every trip has ONE round of
+        // loads in flight: up to kGridBatch records of the current cell (self-contained: centre, r*r and the sphere's index
+        // in r*r's 29 zero mantissa bits) and the list offsets of the NEXT cell on the ray, which do not depend on the tests.
+        const double h = G->h, inv_h = G->inv_h;
+        const int nx = G->dim[0], ny = G->dim[1], nz = G->dim[2];
+        auto cell_of = [&](const double p, const double lo, const int dim) {
+            const int c = (int)floor((p - lo) * inv_h);
+            return c < 0 ? 0 : (c >= dim ? dim - 1 : c);
+        };
+        ix = cell_of(org.x + dir.x * t0, lox, nx);
+        iy = cell_of(org.y + dir.y * t0, loy, ny);
+        iz = cell_of(org.z + dir.z * t0, loz, nz);
+        tmx = dir.x == 0.0 ? inf : ((lox + (double)(ix + (dir.x > 0.0 ? 1 : 0)) * h) - org.x) * invx;
+        tmy = dir.y == 0.0 ? inf : ((loy + (double)(iy + (dir.y > 0.0 ? 1 : 0)) * h) - org.y) * invy;
+        tmz = dir.z == 0.0 ? inf : ((loz + (double)(iz + (dir.z > 0.0 ? 1 : 0)) * h) - org.z) * invz;
+        tdx = dir.x == 0.0 ? inf : h * invx;  // (signed: the direction of the index step rides on the sign)
+        tdy = dir.y == 0.0 ? inf : h * invy;
+        tdz = dir.z == 0.0 ? inf : h * invz;
+        j = jend = nj = nje = 0u;
+        t_exit = 0.0;
+        next_ok = false;
+        if (live) {
+            const unsigned* cs = G->cell_start;
+            const unsigned cell = ((unsigned)iz * ny + iy) * nx + ix;
+            j = cs[cell];
+            jend = cs[cell + 1];
+            plan_next(G);  // (ix, iy, iz, tm* now describe the NEXT cell; t_exit is the current one's)
+        }
+        return live;
+    }
+    // One trip: move on when the current cell is done, then test up to kGridBatch of the cell's records.
+    // Returns whether the walk goes on (false: dis / best are final).
+    __device__ __forceinline__ bool advance(const Scene& sc, const D3 org, const D3 dir) {
+        HdrPtr G = header(sc);
+        if (j >= jend) {
+            // this cell is done: every sphere that can be hit before its exit has been tested (see above)
+            if (dis <= t_exit || !next_ok) return false;
+            if constexpr (COUNT) ++steps;
+            j = nj;
+            jend = nje;
+            plan_next(G);
+        }
+        // A lane with fewer records left than the batch reads on into the following lists (clamped to the table): testing
+        // a sphere that is not in the cell is harmless, the result is the minimum over ALL spheres.
+        const double4* recs = G->recs;
+        const unsigned last_rec = G->n_recs - 1u;
+        const unsigned left = jend - j;  // (0 for a lane in an empty cell: it still rides along, harmlessly)
+        double4 r[kGridBatch];
+#pragma unroll
+        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) r[k] = recs[j + k < last_rec ? j + k : last_rec];
+#pragma unroll
+        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
+            if (__builtin_amdgcn_ballot_w64(left > k) != 0) {
+                // the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
+                const unsigned long long w = (unsigned long long)__double_as_longlong(r[k].w);
+                double4 g = r[k];
+                g.w = __longlong_as_double((long long)(w & ~0x1FFFFFFFull));
+                consider((int)((unsigned)w & 0x1FFFFFFFu), g, org, dir);
+            }
+        }
+        j = left > (unsigned)kGridBatch ? j + (unsigned)kGridBatch : jend;
+        return true;
+    }
+};
+
+template <class M, class Scene, bool COUNT = false>
+__device__ __forceinline__ int nearest_hit_grid(const Scene& sc, const D3 org, const D3 dir, double& dis,
+                                                unsigned* n_tests = nullptr, unsigned* n_steps = nullptr) {
+    GridWalk<M, Scene, COUNT> W;
+    bool walking = W.begin(sc, org, dir);
+    while (walking) walking = W.advance(sc, org, dir);
+    if constexpr (COUNT) {
+        *n_tests = W.tests;
+        *n_steps = W.steps;
+    }
+    dis = W.dis;
+    return W.best;
+}
+
 template <class M, int UNROLL, class Scene>
-__device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
+__device__ __forceinline__ int nearest_hit_loop(const Scene& sc, const D3 org, const D3 dir, double& dis) {
     int hit_object = -1;
     dis = DBL_MAX;
     const int n = sc.n();
@@ -881,6 +1109,14 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
         }
     }
     return hit_object;
+}
+
+template <class M, int UNROLL, class Scene>
+__device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
+    if constexpr (UNROLL == kUnrollGrid)
+        return nearest_hit_grid<M>(sc, org, dir, dis);
+    else
+        return nearest_hit_loop<M, UNROLL>(sc, org, dir, dis);
 }
 
 struct PathCounters {

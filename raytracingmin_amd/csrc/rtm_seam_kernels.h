@@ -131,6 +131,28 @@ __global__ __launch_bounds__(256) void nearest_probe_kernel(SceneView scene, con
     }
 }
 
+// nearest_hit_grid on caller-supplied rays, with its per-ray work counts (rtm_debug_grid_nearest)
+__global__ __launch_bounds__(256) void grid_probe_kernel(SceneView scene, const double* __restrict__ org,
+                                                         const double* __restrict__ dir, unsigned n_rays,
+                                                         int* __restrict__ out_id, double* __restrict__ out_t,
+                                                         unsigned* __restrict__ out_tests, unsigned* __restrict__ out_steps) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned r = i < n_rays ? i : n_rays - 1u;
+    SceneGlobal sc;
+    sc.v = scene;
+    double dis;
+    unsigned tests, steps;
+    const int id = nearest_hit_grid<MathFast, SceneGlobal, true>(sc, d3(org[r], org[n_rays + r], org[2 * (size_t)n_rays + r]),
+                                                                 d3(dir[r], dir[n_rays + r], dir[2 * (size_t)n_rays + r]), dis,
+                                                                 &tests, &steps);
+    if (i < n_rays) {
+        out_id[i] = id;
+        out_t[i] = dis;
+        if (out_tests) out_tests[i] = tests;
+        if (out_steps) out_steps[i] = steps;
+    }
+}
+
 template <class M, int UNROLL>
 __global__ __launch_bounds__(64) void nearest_bench_kernel(SceneView scene, D3 org0, int reps, double* out,
                                                            unsigned long long* cycles) {

@@ -1,0 +1,275 @@
+"""The uniform-grid nearest-hit search of large scenes (variant 17, csrc/rtm_path.h: nearest_hit_grid): the hit object
+and distance of the reference's loop over ALL objects (src/Renderer.cpp:58-73) from a fraction of its Intersect calls.
+Rays: the probe against the reference loop on the GPU (rtm_debug_wf_nearest kind 1) and the oracle; frames: against
+the oracle and the exhaustive kernels, bit for bit with the counters."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rtm():
+    import raytracingmin_amd
+    return raytracingmin_amd
+
+
+def _ref_nearest(rtm, sph, n, org, d):
+    from raytracingmin_amd import _lib
+    org = np.ascontiguousarray(org, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    ids = np.zeros(len(org), dtype=np.int32)
+    t = np.zeros(len(org), dtype=np.float64)
+    _lib.check(rtm.lib().rtm_debug_wf_nearest(1, sph, n, org.ctypes.data, d.ctypes.data, len(org), ids.ctypes.data,
+                                              t.ctypes.data), "reference loop")
+    return ids, t
+
+
+def _grid_nearest(rtm, sph, n, org, d):
+    from raytracingmin_amd import _lib
+    org = np.ascontiguousarray(org, dtype=np.float64)
+    d = np.ascontiguousarray(d, dtype=np.float64)
+    ids = np.zeros(len(org), dtype=np.int32)
+    t = np.zeros(len(org), dtype=np.float64)
+    tests = np.zeros(len(org), dtype=np.uint32)
+    steps = np.zeros(len(org), dtype=np.uint32)
+    info = np.zeros(6, dtype=np.uint64)
+    _lib.check(rtm.lib().rtm_debug_grid_nearest(sph, n, org.ctypes.data, d.ctypes.data, len(org), ids.ctypes.data,
+                                                t.ctypes.data, tests.ctypes.data, steps.ctypes.data, info.ctypes.data),
+               "grid nearest")
+    return ids, t, tests, steps, info
+
+
+def _normalize_like_the_reference(v):
+    """src/Ray.h:67-72: a / (double)sqrtf((float)(a.a))"""
+    m = np.sqrt((v * v).sum(axis=1).astype(np.float32)).astype(np.float64)
+    return v / m[:, None]
+
+
+def _spheres(rtm, centers, radii):
+    from raytracingmin_amd import _lib
+    n = len(radii)
+    arr = (_lib.rtm_sphere * n)()
+    for i in range(n):
+        for k in range(3):
+            arr[i].center[k] = float(centers[i, k])
+            arr[i].color[k] = 0.5
+        arr[i].radius = float(radii[i])
+    return arr
+
+
+def _ray_mix(rng, c, r, count, box):
+    """Rays of every kind the render produces, and some it does not: from outside towards the scene (primary-like),
+    from sphere surfaces outwards (bounce-like, t1 ~ 0), from inside spheres, silhouette grazes with the discriminant
+    swept through zero, axis-parallel directions (zero components), rays that miss the scene's box, rays starting on
+    cell-boundary-like round coordinates."""
+    n = len(r)
+    o = np.empty((count, 3))
+    d = np.empty((count, 3))
+    for k in range(count):
+        kind = k % 8
+        i = int(rng.integers(n))
+        if kind == 0:    # camera-like
+            o[k] = rng.uniform(-1.6, 1.6, 3) * box
+            d[k] = c[i] + rng.normal(size=3) * r[i] - o[k]
+        elif kind == 1:  # bounce-like: from the surface, outwards
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            o[k] = c[i] + nrm * r[i]
+            v = rng.normal(size=3)
+            d[k] = v if v @ nrm > 0 else -v
+        elif kind == 2:  # from inside a sphere
+            o[k] = c[i] + rng.uniform(-0.5, 0.5, 3) * r[i]
+            d[k] = rng.normal(size=3)
+        elif kind == 3:  # silhouette graze
+            o[k] = rng.uniform(-1.2, 1.2, 3) * box
+            P = c[i] - o[k]
+            L = np.linalg.norm(P)
+            e = np.cross(P, rng.normal(size=3))
+            e /= np.linalg.norm(e)
+            delta = (10.0 ** rng.uniform(-17, 0)) * rng.choice([-1.0, 1.0])
+            s = math.sqrt(max(r[i] * r[i] + delta, 0.0)) / max(L, 1e-9)
+            d[k] = (math.sqrt(1 - s * s) * P / L + s * e) if s < 1 else rng.normal(size=3)
+        elif kind == 4:  # axis-parallel
+            o[k] = rng.uniform(-1.0, 1.0, 3) * box
+            d[k] = 0.0
+            d[k, int(rng.integers(3))] = rng.choice([-1.0, 1.0])
+        elif kind == 5:  # one zero component, round origin coordinates
+            o[k] = np.round(rng.uniform(-1.0, 1.0, 3) * box)
+            d[k] = rng.normal(size=3)
+            d[k, int(rng.integers(3))] = 0.0
+        elif kind == 6:  # pointing away from / past the scene
+            o[k] = rng.uniform(1.05, 1.5, 3) * box * rng.choice([-1.0, 1.0], 3)
+            d[k] = rng.normal(size=3)
+        else:            # anywhere, any direction
+            o[k] = rng.uniform(-1.0, 1.0, 3) * box
+            d[k] = rng.normal(size=3)
+    return o, _normalize_like_the_reference(d)
+
+
+SPECIAL = [([0, 0, 0], [np.nan, 0, 1]), ([np.inf, 0, 0], [0, 0, 1]), ([0, 0, 0], [np.inf, 0, 0]), ([1e200, 0, 0], [1, 0, 0]),
+           ([1e200, 0, 0], [-1, 0, 0]), ([0, 0, 0], [0, 0, 0]), ([0, 0, 0], [1e-200, 0, 0]), ([0, np.nan, 0], [0, 0, 1]),
+           ([0, 0, -1e6], [0, 0, 1]), ([3, 4, -5000], [0, 0, 1])]
+
+
+def _check(rtm, arr, n, o, d, label, max_mean_tests=None):
+    ref_id, ref_t = _ref_nearest(rtm, arr, n, o, d)
+    ids, t, tests, steps, info = _grid_nearest(rtm, arr, n, o, d)
+    bad = np.flatnonzero((ids != ref_id) | (t.view(np.uint64) != ref_t.view(np.uint64)))
+    print(f"{label}: {len(o)} rays, {int((ref_id >= 0).sum())} hit; grid {info[3]}x{info[4]}x{info[5]} = {info[0]} cells, "
+          f"{info[1]} list entries, {info[2]} tested by every ray; per ray {tests.mean():.1f} sphere tests (max {tests.max()}), "
+          f"{steps.mean():.1f} cell steps")
+    assert bad.size == 0, (label, bad[:5], ids[bad[:5]], ref_id[bad[:5]], t[bad[:5]], ref_t[bad[:5]], o[bad[:5]], d[bad[:5]])
+    if max_mean_tests is not None:
+        assert tests.mean() <= max_mean_tests
+    return ref_id, ref_t, tests
+
+
+def test_grid_nearest_is_the_reference_loops_nearest(rtm, oracle):
+    """The stress-scene family at three sizes: every kind of ray, hit object and distance bit for bit, and the work per
+    ray is tens of sphere tests, not n."""
+    rng = np.random.default_rng(171)
+    for n, count in ((400, 60_000), (20_000, 120_000), (100_000, 60_000)):
+        data = rtm.make_stress_scene(n, seed=1000 + n)
+        _, arr, _ = data.to_c()
+        c = np.array([[arr[i].center[k] for k in range(3)] for i in range(n)])
+        r = np.array([arr[i].radius for i in range(n)], dtype=np.float64)
+        o, d = _ray_mix(rng, c, r, count, 50.0)
+        # directions that are not unit length and the non-finite rays: the exhaustive loop / no hit
+        d[::97] *= rng.uniform(0.5, 3.0, (len(d[::97]), 1))
+        o = np.concatenate([o, np.array([s[0] for s in SPECIAL], dtype=np.float64)])
+        d = np.concatenate([d, np.array([s[1] for s in SPECIAL], dtype=np.float64)])
+        ref_id, ref_t, tests = _check(rtm, arr, n, o, d, f"stress n={n}")
+        hit = ref_id >= 0
+        assert 0.15 < hit.mean() < 0.995
+        unit = np.ones(len(o), dtype=bool)
+        unit[:count:97] = False
+        unit[count:] = False
+        if n >= 20_000:
+            assert tests[unit].mean() < 150  # (the exhaustive rays take n each)
+        # the oracle's Intersect on a sample: the reported sphere gives the reported distance
+        oarr = (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+        for k in rng.choice(np.flatnonzero(hit & unit), 200, replace=False):
+            h, tt, _ = oracle.intersect(oarr[int(ref_id[k])], o[k], d[k], oracle.MODE_REPAIRED)
+            assert h and tt == ref_t[k]
+
+
+def test_grid_nearest_awkward_scenes(rtm, oracle):
+    """Scenes a uniform grid does not like: spheres that span the scene and of radius 0 (tested by every ray), exact
+    duplicates and concentric shells (ties: the lowest index must win, src/Renderer.cpp:67), everything in one plane
+    (a grid one cell thick), two far-apart clusters, radii over three orders of magnitude, centres on round numbers."""
+    rng = np.random.default_rng(172)
+    scenes = {}
+    # (a) small spheres + walls of radius 1e4 around them + zero-radius spheres + duplicates
+    n = 3000
+    c = rng.uniform(-20, 20, (n, 3))
+    r = rng.uniform(0.1, 1.5, n)
+    c[:6] = [[0, 0, 1e4 + 25], [0, 0, -1e4 - 25], [1e4 + 25, 0, 0], [-1e4 - 25, 0, 0], [0, 1e4 + 25, 0], [0, -1e4 - 25, 0]]
+    r[:6] = 1e4
+    r[6:30] = 0.0
+    c[1000:1100] = c[900:1000]   # exact duplicates at higher indices
+    r[1000:1100] = r[900:1000]
+    c[1100:1150] = c[850:900]    # concentric: same centre, other radius
+    scenes["walls+zero+duplicates"] = (c, r, 25.0)
+    # (b) flat: all centres in the plane z = 0
+    n = 2000
+    c = rng.uniform(-30, 30, (n, 3))
+    c[:, 2] = 0.0
+    scenes["flat"] = (c, rng.uniform(0.2, 0.9, n), 30.0)
+    # (c) two clusters far apart + radii from 0.01 to 10
+    n = 4000
+    c = np.concatenate([rng.normal(size=(n // 2, 3)) * 5 + [-200, 0, 0], rng.normal(size=(n // 2, 3)) * 8 + [300, 50, -40]])
+    scenes["clusters"] = (c, 10.0 ** rng.uniform(-2, 1, n), 350.0)
+    # (d) lattice: centres on integers, radius 0.25 (rays along cell boundaries)
+    g = np.arange(-6, 7)
+    c = np.array([[x, y, z] for x in g for y in g for z in g], dtype=np.float64)
+    scenes["lattice"] = (c, np.full(len(c), 0.25), 8.0)
+    for name, (c, r, box) in scenes.items():
+        n = len(r)
+        arr = _spheres(rtm, c, r)
+        o, d = _ray_mix(rng, c, np.maximum(r, 1e-3), 40_000, box)
+        if name == "lattice":  # rays exactly along the lattice planes and through rows of centres
+            o[:4000] = np.round(o[:4000] * 2) / 2
+            d[:4000] = 0.0
+            d[np.arange(4000), rng.integers(0, 3, 4000)] = rng.choice([-1.0, 1.0], 4000)
+        o = np.concatenate([o, np.array([s[0] for s in SPECIAL], dtype=np.float64)])
+        d = np.concatenate([d, np.array([s[1] for s in SPECIAL], dtype=np.float64)])
+        ref_id, ref_t, _ = _check(rtm, arr, n, o, d, name)
+        assert (ref_id >= 0).mean() > 0.2
+        if name == "walls+zero+duplicates":  # ties really occur, and go to the lower index
+            assert not np.isin(ref_id, np.arange(1000, 1100)).any() and np.isin(ref_id, np.arange(900, 1000)).any()
+
+
+def _oracle_view(oracle, data):
+    st, arr, n = data.to_c()
+    return oracle.Settings.from_buffer_copy(bytes(st)), (oracle.Sphere * max(n, 1)).from_buffer_copy(bytes(arr)), n
+
+
+def _image(rtm, data, mode, mb, seed, variant, rows=None, want=("f64",)):
+    r = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=variant)
+    rb, re = rows if rows else (0, data.height)
+    return r.render_rows(rb, re, want=want)
+
+
+@pytest.mark.parametrize("n,w,h,s", [(300, 64, 40, 4), (3000, 48, 32, 4), (100_000, 32, 16, 2)])
+@pytest.mark.parametrize("mb", [8, -1])
+def test_grid_frames_vs_oracle(rtm, oracle, n, w, h, s, mb):
+    """Whole frames of the stress-scene family through the grid kernel: the oracle's image and counters, in both modes,
+    and what variant 0 picks for these sizes."""
+    data = rtm.make_stress_scene(n=n, seed=12345)
+    data.width, data.height, data.samples, data.superSamples = w, h, s, 1
+    ost, oarr, _ = _oracle_view(oracle, data)
+    for mode, omode in (("repaired", 1), ("literal", 0)):
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=omode, max_bounces=mb, seed=5, height=h))
+        for variant in (17, 0):
+            out, st = _image(rtm, data, mode, mb, 5, variant, want=("f64", "u8"))
+            assert st["variant"] == (17 if (variant == 17 or n >= 512) else 3)
+            assert np.array_equal(out["f64"].view(np.uint64), ref.view(np.uint64)), (mode, variant)
+            assert np.array_equal(out["u8"], oracle.quantise(ref))
+            assert (st["casts"], st["bounces"], st["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"])
+
+
+def test_grid_frame_row_ranges_and_bands(rtm, oracle):
+    """Row ranges and the multi-GPU deal of 8-row bands: the parts are the frame."""
+    from raytracingmin_amd.distributed import band_row_index
+    data = rtm.make_stress_scene(n=5000, seed=3)
+    data.width, data.height, data.samples, data.superSamples = 70, 45, 2, 2
+    full, st_full = _image(rtm, data, "repaired", 8, 3, 17)
+    wf, st_wf = _image(rtm, data, "repaired", 8, 3, 12)
+    assert np.array_equal(full["f64"], wf["f64"]) and st_full["casts"] == st_wf["casts"]
+    for lo, hi, world in ((0, 45, 3), (8, 42, 2)):
+        got = np.full_like(full["f64"], np.nan)
+        for rank in range(world):
+            r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3, variant=17)
+            out, _ = r.render_rows(lo, hi, want=("f64",), band=(world, rank))
+            got[band_row_index(lo, hi, world, rank)] = out["f64"]
+        assert np.array_equal(got[lo:hi], full["f64"][lo:hi])
+
+
+def test_grid_is_refused_where_there_is_none(rtm, oracle):
+    small = rtm.make_stress_scene(n=100, seed=1)
+    small.width, small.height, small.samples, small.superSamples = 16, 16, 1, 1
+    with pytest.raises(rtm.RtmError, match="grid"):
+        _image(rtm, small, "repaired", 8, 1, 17)
+
+
+def test_config5_strip_grid_vs_pipeline_and_spot_pixels(rtm, oracle):
+    """BASELINE configs[4] (100 000 spheres, 1920x1080 @ 256 spp, cap 8): a 16-row strip through the grid kernel and
+    through the exhaustive large-scene pipeline — the same bits and counters — and pixels against the oracle."""
+    data = rtm.make_stress_scene(n=100_000, seed=12345)
+    W, H = 1920, 1080
+    data.width, data.height, data.samples, data.superSamples = W, H, 256, 1
+    rows = (532, 548)
+    g, gs = _image(rtm, data, "repaired", 8, 0x5EED, 17, rows=rows)
+    p, ps = _image(rtm, data, "repaired", 8, 0x5EED, 12, rows=rows)
+    print(f"configs[4] rows {rows}: grid {gs['kernel_ms']:.1f} ms, exhaustive pipeline {ps['kernel_ms']:.1f} ms "
+          f"({ps['kernel_ms'] / gs['kernel_ms']:.0f}x), {gs['casts'] / gs['samples']:.3f} casts/sample")
+    assert np.array_equal(g["f64"].view(np.uint64), p["f64"].view(np.uint64))
+    assert {k: gs[k] for k in ("samples", "casts", "bounces", "draws")} == {k: ps[k] for k in ("samples", "casts", "bounces", "draws")}
+    rng = np.random.default_rng(6)
+    xy = np.stack([rng.integers(0, W, 24), rng.integers(rows[0], rows[1], 24)], axis=1).astype(np.int32)
+    ost, oarr, n = _oracle_view(oracle, data)
+    ref, _ = oracle.render_pixels(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=0x5EED, height=H), xy)
+    assert np.array_equal(g["f64"][xy[:, 1] - rows[0], xy[:, 0]].view(np.uint64), ref.view(np.uint64))
