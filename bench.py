@@ -146,9 +146,9 @@ def valu_issue_view(pmc, source):
             "measured_in_run": False, "source": source}
 
 
-def other_configs(rtm, cfg, device, host_trig, full_c5=True):
-    """BASELINE configs[1], configs[4] (the full frame unless --no-full-c5, and a strip), the plane scene and the two
-    labelled rows, measured in this run, outside the timed region.  Every group of rows stands alone: a failure is
+def other_configs(rtm, cfg, device, host_trig, full_c5=False):
+    """BASELINE configs[1], configs[4] (the full frame through the grid kernel, a strip — the full frame with
+    --full-c5-exhaustive — through the exhaustive pipeline), the plane scene and the two labelled rows, measured in this run, outside the timed region.  Every group of rows stands alone: a failure is
     recorded under its name and the others are still measured."""
     import torch
     out = {"measured_in_run": True}
@@ -231,12 +231,37 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=True):
     def c5():
         stress = rtm.make_stress_scene(n=100_000, seed=12345)
         stress.width, stress.height, stress.samples, stress.superSamples = 1920, 1080, 256, 1
+        # BASELINE configs[4] as named: the whole 1080p frame at 256 spp, as variant 0 renders it — the uniform-grid
+        # kernel: the reference loop's nearest hit for every cast (same image bit for bit, tests/test_grid_gpu.py) from
+        # tens of Intersect calls instead of 100 000
         r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
-        r.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: scene upload, buffers
+        dt, st = timed(r, 3)
+        row = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
+               "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+               "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
+               "note": ("the nearest hit of the reference's loop over all 100 000 spheres (src/Renderer.cpp:58-73) found "
+                        "through a uniform grid: fewer sphere tests than the reference makes, the same hit object, distance "
+                        "and image; the row below is the exhaustive kernel")}
+        gpath = os.path.join(ROOT, "profiles", "r3", "c5_grid_pmc_summary.json")
+        if os.path.exists(gpath):
+            gj = json.load(open(gpath))
+            if "FETCH_SIZE" in gj and "WRITE_SIZE" in gj:
+                row["traffic"] = (gj["FETCH_SIZE"] + gj["WRITE_SIZE"]) * 1024.0
+                row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_grid_pmc_summary.json",
+                                         "note": "FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; "
+                                                 "profiles/prof_c5_grid.sh): L2 misses of the 22 MB cell lists, served "
+                                                 "mostly by the Infinity Cache"}
+        out["c5_stress_100k_full_1080p_256spp"] = row
+
+        # the exhaustive large-scene pipeline (variant 12: every cast tests all 100 000 spheres, packed-fp32 rejection
+        # in front of the exact test) on a strip; the whole frame takes ~24 s (--full-c5-exhaustive)
+        rx = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig,
+                          variant=12)
+        rx.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: buffers
 
         def c5_row(lo, hi):
             t0 = time.perf_counter()
-            _, st = r.render_rows_device(lo, hi, want=("f32",), stats=True)
+            _, st = rx.render_rows_device(lo, hi, want=("f32",), stats=True)
             dt = time.perf_counter() - t0
             tests_per_s = st["casts"] * 100_000 / dt
             return {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
@@ -247,9 +272,8 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=True):
         row = c5_row(508, 572)
         row["note"] = ("a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the "
                        "chip (DESIGN.md §4)")
-        out["c5_stress_100k_rows_508_572_of_1080p_256spp"] = row
+        out["c5_stress_100k_exhaustive_rows_508_572_of_1080p_256spp"] = row
         if full_c5:
-            # BASELINE configs[4] as named: the whole 1080p frame at 256 spp, one timed step (~23 s)
             row = c5_row(0, 1080)
             row["traffic"] = None
             tpath = os.path.join(ROOT, "profiles", "r3", "c5_traffic.json")
@@ -257,7 +281,7 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=True):
                 tj = json.load(open(tpath))
                 row["traffic"] = tj["bytes_per_frame"]
                 row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_traffic.json", "note": tj.get("note")}
-            out["c5_stress_100k_full_1080p_256spp"] = row
+            out["c5_stress_100k_exhaustive_full_1080p_256spp"] = row
 
     guarded("c2_cornell_512x512_256spp", c2)
     guarded("LABELLED_headline_frame_with_primary_hit_reuse", reuse_row)
@@ -324,9 +348,11 @@ def main():
                          "bit-identical either way (tests/test_parity_gpu.py), adversarial scenes are not")
     ap.add_argument("--host-trig", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-extras", action="store_true", help="skip with_d2h and other_configs")
-    ap.add_argument("--no-full-c5", action="store_true",
-                    help="other_configs: skip the full 1080p x 256 spp frame of the 100k-sphere scene (~25 s plus ~25 s of warm-up "
-                         "inside the strip rows); the 64-row strip is still measured")
+    ap.add_argument("--no-full-c5", action="store_true", help="(kept for old command lines: the full frame of the 100k-sphere "
+                                                              "scene is a quarter of a second through the grid kernel)")
+    ap.add_argument("--full-c5-exhaustive", action="store_true",
+                    help="other_configs: also render the full 1080p x 256 spp frame of the 100k-sphere scene through the "
+                         "exhaustive pipeline (variant 12, ~24 s); its 64-row strip is always measured")
     ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
                     help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
@@ -594,7 +620,7 @@ def main():
                                         "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
         if world == 1 and not args.no_extras and headline:
             try:
-                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=not args.no_full_c5)
+                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=args.full_c5_exhaustive)
             except Exception as exc:
                 extras_failed["other_configs"] = repr(exc)
         if extras_failed:

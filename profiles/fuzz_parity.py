@@ -28,7 +28,7 @@ def sphere(pos, r, col):
 bad = 0
 for case in range(cases):
     n = int(rng.choice([1, 2, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
-                        513, 1000]))
+                        513, 1000, 2500]))
     kind = case % 4
     if kind == 3:  # planes and spheres mixed, in a room
         n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 24, 25, 40, 100, 254]))
@@ -65,7 +65,12 @@ for case in range(cases):
     mb = int(rng.choice([-1, -1, 0, 1, 2, 7, 8, 9, 15, 16, 17, 40, 200]))
     mode = "literal" if case % 5 == 4 else "repaired"
     seed = int(rng.integers(1 << 40))
+    if n >= 1000:  # (the oracle's loop over all spheres: keep the frame small)
+        data.width, data.height = int(rng.integers(1, 40)), int(rng.integers(1, 24))
+        data.samples, data.superSamples = int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2]))
     variant = int(rng.choice([0, 0, 0, 2, 9, 14, 3, 12]))
+    if n >= 300 and case % 2 == 0:
+        variant = 17  # the uniform-grid kernel by name (variant 0 picks it from 512 spheres on)
     if case % 7 == 3 and 1 <= n <= 24 and 0 <= mb <= 8 and mode == "repaired":
         variant = 15  # the labelled primary-hit-reuse row must give the same bits where it applies
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED

@@ -1,0 +1,173 @@
+// Large scenes through the uniform grid (variant 17): the render kernel and its finalize pass.
+//
+// The pixel/sample loop nest of src/Renderer.cpp:215-250 with PathTracing (:57-117) underneath, like render_tiles_kernel,
+// but shaped by what a grid walk costs: the walk of one ray (rtm_path.h: GridWalk) takes a number of trips that is
+// exponentially distributed (the free path), and pixels differ by 2-3x in casts per sample (a pixel whose primary ray
+// ends on a light takes one cast per sample, its neighbour three).  A wave that keeps lane = pixel and shades its 64
+// lanes in lockstep therefore runs at a quarter of its lanes (measured: 24 % active lanes, profiles/r3/README.md).  So:
+//
+//   * one wave per 8x8 tile, but a lane is not tied to a pixel: the tile's (pixel, sample) pairs — 64 x spp UNITS, in
+//     sample-major order — are dealt to lanes as they become free (an LDS counter).  The counter RNG is keyed by
+//     (seed, global pixel, sample, draw), so any lane can trace any unit; all 64 lanes finish within one unit of each
+//     other whatever the pixels cost.
+//   * lanes walk independently and are shaded in groups: each trip of the loop advances the walks until at least
+//     kGridShadeAt8 / 8 of the busy lanes have finished theirs, shades those (they start their next ray, or fold their
+//     path and take the next unit) and leaves the others walking.
+//   * the sum over a pixel's samples must be added in sample order (src/Renderer.cpp:241-242; fp64 addition does not
+//     commute bitwise), and the samples of a pixel now finish on different lanes in any order: every sample's term
+//     (cal / SS / SS / S, clamped — :240) goes to memory, [tile][sample][pixel][3] doubles, and grid_finalize_kernel
+//     adds them per pixel in sample order and stores the pixel.  24 bytes per sample written once and read once,
+//     coalesced on the read side: 25 GB for the 5.3e8 samples of BASELINE configs[4], 3 % of the frame's time.
+#ifndef RTM_GRID_KERNEL_H
+#define RTM_GRID_KERNEL_H
+
+#include "rtm_render_kernel.h"
+
+namespace rtm {
+
+#ifndef RTM_GRID_WPE
+#define RTM_GRID_WPE 4
+#endif
+constexpr int kGridWavesPerSimd = RTM_GRID_WPE;  // launch bound of the grid kernel (profiles/r3/grid_variants.txt)
+__host__ __device__ inline size_t grid_tile_term_bytes(unsigned total_samples) { return (size_t)total_samples * 64 * 3 * sizeof(double); }
+
+// tile of block b: blocks are dealt round-robin to the 8 XCDs, each with its own L2 (RenderParams::xcd_on)
+__device__ __forceinline__ unsigned grid_tile_of_block(const RenderParams& P, unsigned b) {
+    if (P.xcd_on) {
+        const unsigned xcd = b & 7u;
+        b = xcd * P.xcd_q + (xcd < P.xcd_rem ? xcd : P.xcd_rem) + (b >> 3);
+    }
+    return b;
+}
+
+// blockIdx.x: index into this launch's tiles [tile_base, tile_base + gridDim.x); terms: P.contrib, gridDim.x tiles
+template <typename RecT, int LDS_D>
+__global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(const RenderParams P, const unsigned tile_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    double* cam = reinterpret_cast<double*>(lds_raw);  // 9 camera doubles + pad
+    double* trig = cam + 10;                           // 16 sincos constants
+    RecT* rec = reinterpret_cast<RecT*>(trig + kTrigConstCount);
+    unsigned* next_unit = reinterpret_cast<unsigned*>(rec + LDS_D * 64);
+    if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
+    if (lane < 9) {
+        const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
+        double pick = v9[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) pick = (lane == k) ? v9[k] : pick;
+        cam[lane] = pick;
+    }
+    if (lane == 0) *next_unit = 0u;
+    __syncthreads();
+
+    SceneGlobal sc;
+    sc.v = P.scene;
+    const unsigned local_tile = grid_tile_of_block(P, blockIdx.x);
+    const unsigned tile = tile_base + local_tile;
+    const int tile_x8 = (int)(tile % (unsigned)P.tiles_x) * 8, tile_y = (int)(tile / (unsigned)P.tiles_x);
+    const unsigned total_units = P.total_samples * 64u;
+    double* const terms = reinterpret_cast<double*>(P.contrib) + (size_t)local_tile * P.total_samples * 192;
+
+    PathCounters pc = {0, 0, 0};
+    RecordStack<RecT, LDS_D> stack{rec, lane, &P};
+    auto push = [&](int d, int id) { stack.push(d, id); };
+    auto pop = [&](int d) -> int { return stack.pop(d); };
+    const bool pow2 = P.inv_s != 0.0;  // wave-uniform
+
+    // this lane's unit and path
+    unsigned unit = 0;
+    D3 org = P.cam_org, dir = d3(0, 0, 1);
+    int depth = 0;
+    RngStream rng = rng_open(rng_pixel_key(P.seed_mult, 0u), 0u);
+    // Take the next unit of the tile whose pixel is inside the frame and set its primary ray up (:224-232).
+    auto take_unit = [&]() -> bool {
+        int px, py;
+        for (;;) {
+            unit = atomicAdd(next_unit, 1u);
+            if (unit >= total_units) return false;
+            px = tile_x8 + (int)(unit & 7u);
+            py = band_row(P, tile_y, (int)((unit >> 3) & 7u));
+            if (px < P.W && py < P.row_end) break;
+        }
+        const unsigned s = unit >> 6;  // sample index ((sx-1)*SS + (sy-1))*S + s
+        const int sub = (int)(s / (unsigned)P.S);
+        org = P.cam_org;
+        dir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+        depth = 0;
+        rng = rng_open(rng_pixel_key(P.seed_mult, (uint32_t)py * (uint32_t)P.W + (uint32_t)px), s);
+        return true;
+    };
+    bool busy = take_unit();
+    GridWalk<MathFast, SceneGlobal> walk;
+    bool walking = false;
+    while (__builtin_amdgcn_ballot_w64(busy) != 0) {  // wave-uniform
+        if (busy && !walking) walking = walk.begin(sc, org, dir);
+        for (;;) {
+            const unsigned n_busy = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(busy));
+            const unsigned n_walk = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking));
+            if (n_walk * 8u <= n_busy * (8u - (unsigned)kGridShadeAt8)) break;
+            if (walking) walking = walk.advance(sc, org, dir);
+        }
+        if (busy && !walking) {
+            D3 term;
+            bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+            if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
+                cont = false;
+                term = d3(0, 0, 0);
+                depth = 0;
+            }
+            if (!cont) {
+                const bool deep = depth > LDS_D;
+                const D3 L = (__builtin_amdgcn_ballot_w64(deep) == 0)
+                                 ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
+                                 : path_fold(sc, term, depth, pop);
+                // :240 cal / SS / SS / S (power-of-two divisors as exact multiplications), :241 the clamp
+                const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
+                const D3 add = clamp01_d3(cal);
+                double* t = terms + (size_t)unit * 3;  // unit = sample * 64 + pixel
+                __builtin_nontemporal_store(add.x, t);
+                __builtin_nontemporal_store(add.y, t + 1);
+                __builtin_nontemporal_store(add.z, t + 2);
+                busy = take_unit();
+            }
+        }
+    }
+    if (P.counters) {
+        wave_add_counter(P.counters + 0, pc.casts);
+        wave_add_counter(P.counters + 1, pc.bounces);
+        wave_add_counter(P.counters + 2, pc.draws);
+        if (stack.overflow) atomicOr(P.counters + 3, 1ull);
+    }
+}
+
+// image[pixel] = ((0 + term[0]) + term[1]) + ... in sample order (src/Renderer.cpp:241-248).  One wave per tile, lane =
+// pixel; a sample's 64 terms are one contiguous 1 536-byte row.
+__global__ __launch_bounds__(64) void grid_finalize_kernel(const RenderParams P, const unsigned tile_base) {
+    const int lane = threadIdx.x;
+    const unsigned tile = tile_base + blockIdx.x;
+    const int px = (int)(tile % (unsigned)P.tiles_x) * 8 + (lane & 7);
+    const int py = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);
+    const bool valid = px < P.W && py < P.row_end;
+    if (!valid) return;  // (its units were never traced: the rows hold nothing for it)
+    const double* t = reinterpret_cast<const double*>(P.contrib) + (size_t)blockIdx.x * P.total_samples * 192 + lane * 3;
+    D3 acc = d3(0, 0, 0);
+    unsigned s = 0;
+    for (; s + 4 <= P.total_samples; s += 4) {  // four rows in flight; the additions stay in order
+        D3 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double* r = t + (size_t)(s + k) * 192;
+            v[k] = d3(__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 2));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = acc + v[k];
+    }
+    for (; s < P.total_samples; ++s) {
+        const double* r = t + (size_t)s * 192;
+        acc = acc + d3(r[0], r[1], r[2]);
+    }
+    store_pixel(P, true, px, py, acc);
+}
+
+}  // namespace rtm
+#endif

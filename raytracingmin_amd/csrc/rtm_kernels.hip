@@ -37,6 +37,7 @@
 #include "rtm_path.h"
 
 #include "rtm_render_kernel.h"
+#include "rtm_grid_kernel.h"
 #include "rtm_wavefront.h"
 #include "rtm_fp32.h"
 #include "rtm_seam_kernels.h"
@@ -297,10 +298,6 @@ static SceneView scene_view(const double* geom, const double* mat, const double*
 // milliseconds for 100 000 spheres, once per scene.  ~kGridCellsPerSphere cells per sphere; a sphere whose padded box
 // covers more than kGridBigCells cells goes to the list every ray tests.  No grid (the other kernels serve the scene)
 // for fewer than kGridMinSpheres spheres, non-finite geometry, more than kGridMaxBig big spheres or planes.
-#ifndef RTM_GRID_WPE
-#define RTM_GRID_WPE 4
-#endif
-constexpr int kGridWavesPerSimd = RTM_GRID_WPE;  // launch bound of the grid kernel (profiles/r3/grid_tune.txt)
 constexpr size_t kGridMinSpheres = 257;  // (ids beyond a byte: the grid kernel is instantiated for u32 records only)
 constexpr int kGridBigCells = 125, kGridMaxBig = 1024, kGridMaxDim = 1024;
 constexpr double kGridDdTol = 4e-7;  // |dir.dir - 1| the pads cover: twice what the reference's float-sqrt Normalize leaves (1.8e-7)
@@ -429,9 +426,17 @@ static bool make_grid(const double* g, size_t n, GridBuild& out) {
             if (is_big[i]) continue;
             int a[3], b[3];
             for (int k = 0; k < 3; ++k) cell_range(i, k, a[k], b[k]);
+            // of the box's cells, those within R + pad of the centre (a hit point is, and lies in its cell)
+            const double reach2 = (R[i] + pad[i]) * (R[i] + pad[i]) * (1.0 + 1e-9);
+            auto gap = [&](int k, int cell) {  // distance from the centre to the cell's slab along axis k
+                const double c0 = H.lo[k] + (double)cell * h, ck = g[i * 4 + k];
+                return ck < c0 ? c0 - ck : (ck > c0 + h ? ck - (c0 + h) : 0.0);
+            };
             for (int z = a[2]; z <= b[2]; ++z)
                 for (int y = a[1]; y <= b[1]; ++y)
                     for (int x = a[0]; x <= b[0]; ++x) {
+                        const double gx = gap(0, x), gy = gap(1, y), gz = gap(2, z);
+                        if (gx * gx + gy * gy + gz * gz > reach2) continue;
                         const size_t c = ((size_t)z * H.dim[1] + y) * H.dim[0] + x;
                         if (pass == 0) {
                             ++out.cell_start[c + 1];
@@ -458,7 +463,13 @@ static int build_scene_grid(rtm_scene& sc, const double* hg, size_t n, int devic
     GridBuild B;
     if (sc.has_planes || !make_grid(hg, n, B)) return RTM_OK;
     const size_t off_cs = (sizeof(GridHeader) + 255) & ~(size_t)255;
-    const size_t off_items = off_cs + ((B.cell_start.size() * sizeof(unsigned) + 255) & ~(size_t)255);
+    const size_t n_cells = B.cell_start.size() - 1;
+    std::vector<unsigned> ranges(n_cells * 2);  // (first, one past last) per cell: one 8-byte load per cell step
+    for (size_t c = 0; c < n_cells; ++c) {
+        ranges[c * 2] = B.cell_start[c];
+        ranges[c * 2 + 1] = B.cell_start[c + 1];
+    }
+    const size_t off_items = off_cs + ((ranges.size() * sizeof(unsigned) + 255) & ~(size_t)255);
     const size_t off_big = off_items + ((B.items.size() * 4 * sizeof(double) + 255) & ~(size_t)255);
     // the cell lists as self-contained records: the geometry row with the sphere's index in r*r's 29 zero mantissa bits
     std::vector<double> recs(B.items.size() * 4);
@@ -474,12 +485,12 @@ static int build_scene_grid(rtm_scene& sc, const double* hg, size_t n, int devic
     const int rc = sc.grid.alloc_pooled(bytes, device);
     if (rc != RTM_OK) return rc;
     unsigned char* base = sc.grid.as<unsigned char>();
-    B.hdr.cell_start = reinterpret_cast<const unsigned*>(base + off_cs);
+    B.hdr.cell_range = reinterpret_cast<const uint2*>(base + off_cs);
     B.hdr.recs = reinterpret_cast<const double4*>(base + off_items);
     B.hdr.n_recs = (unsigned)B.items.size();
     B.hdr.big = reinterpret_cast<const int*>(base + off_big);
     RTM_HIP_CHECK(hipMemcpy(base, &B.hdr, sizeof B.hdr, hipMemcpyHostToDevice));
-    RTM_HIP_CHECK(hipMemcpy(base + off_cs, B.cell_start.data(), B.cell_start.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(base + off_cs, ranges.data(), ranges.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     RTM_HIP_CHECK(hipMemcpy(base + off_items, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
     if (!B.big.empty())
         RTM_HIP_CHECK(hipMemcpy(base + off_big, B.big.data(), B.big.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1076,9 +1087,6 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
         case kVariantStamped:  // render_view: n <= kLdsTableMaxSpheres
             launch_render_depth<MathFast, true, 8, uint8_t, 4, true, true, true>(P, grid, stream);
             return;
-        case kVariantGrid:  // render_view: the scene has a grid (n >= 257)
-            launch_render_depth<MathFast, false, kUnrollGrid, uint32_t, kGridWavesPerSimd>(P, grid, stream);
-            return;
         default:  // kVariantFastGlobal: the chunked kernel with global-memory tables, any n
             if (n <= 256) launch_render_depth<MathFast, false, 8, uint8_t, 4>(P, grid, stream);
             else launch_render_depth<MathFast, false, 8, uint32_t, 4>(P, grid, stream);
@@ -1530,6 +1538,44 @@ int stream_status(int device, void* stream_v) {
 
 // The render proper: `view` is resident on opt->device and stays valid until the queued work has run.
 // The caller holds g_gate (shared).
+// Variant 17 (rtm_grid_kernel.h): the render kernel leaves every sample's term in the stream's term buffer, the finalize
+// kernel adds them per pixel in sample order.  The buffer holds tiles x spp x 1 536 bytes (12.7 GB for the 32 400 tiles of
+// a 1080p frame at 256 spp): beyond kGridTermBudget — or what the device will give — the frame is rendered in several
+// launches of as many tiles as fit, one behind the other on the stream, each followed by its finalize.
+constexpr size_t kGridTermBudget = (size_t)16 << 30;
+static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx) {
+    static const bool xcd_off = [] {
+        const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
+        return e && e[0] == '0';
+    }();
+    const size_t per_tile = grid_tile_term_bytes(P.total_samples);
+    size_t chunk = std::min<size_t>(tiles, std::max<size_t>(1, kGridTermBudget / per_tile));
+    void* ws = nullptr;
+    for (;;) {
+        if (scratch_acquire(ctx, kScratchTerms, chunk * per_tile, &ws) == RTM_OK) break;
+        (void)hipGetLastError();
+        if (chunk <= 64) {
+            set_last_error("no device memory for the grid kernel's term buffer");
+            return RTM_ERR_HIP;
+        }
+        chunk = (chunk + 1) / 2;
+    }
+    P.contrib = static_cast<unsigned char*>(ws);
+    const bool deep = needs_pool(P);
+    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 + debug_lds_pad();
+    for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
+        const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);
+        P.xcd_on = xcd_off ? 0u : 1u;
+        P.xcd_q = cnt / 8u;
+        P.xcd_rem = cnt % 8u;
+        if (deep) render_grid_kernel<uint32_t, 32><<<cnt, 64, lds, ctx.stream>>>(P, base);
+        else render_grid_kernel<uint32_t, 16><<<cnt, 64, lds, ctx.stream>>>(P, base);
+        grid_finalize_kernel<<<cnt, 64, 0, ctx.stream>>>(P, base);
+    }
+    RTM_HIP_CHECK(hipGetLastError());
+    return RTM_OK;
+}
+
 static int render_view(const rtm_settings* st, const SceneView& view, size_t n, const rtm_options* opt,
                        double* out64, float* out32, uint8_t* out8, hipStream_t stream, rtm_stats* stats) {
     RTM_HIP_CHECK(hipSetDevice(opt->device));
@@ -1689,15 +1735,6 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         P.stamps = stamps.as<unsigned long long>();
     }
 
-    if (variant == kVariantGrid) {
-        static const bool xcd_off = [] {
-            const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
-            return e && e[0] == '0';
-        }();
-        P.xcd_on = xcd_off ? 0u : 1u;
-        P.xcd_q = grid / 8u;
-        P.xcd_rem = grid % 8u;
-    }
     EventPair ev;
     if (stats) {
         rc = ev.create();
@@ -1706,6 +1743,9 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     }
     if (variant == kVariantWavefrontRejectF32) {
         rc = run_wavefront(P, rows, ctx, stats != nullptr);
+        if (rc != RTM_OK) return rc;
+    } else if (variant == kVariantGrid) {
+        rc = run_grid(P, grid, ctx);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, stream);

@@ -467,7 +467,7 @@ struct GridHeader {
     int dim[3];
     int n_big;
     unsigned n_recs, pad_;
-    const unsigned* cell_start;  // dim[0]*dim[1]*dim[2] + 1 offsets into `recs`
+    const uint2* cell_range;     // per cell (dim[0]*dim[1]*dim[2] of them): first and one-past-last entry of its list in `recs`
     const double4* recs;         // a cell's spheres, self-contained: (cx, cy, cz, r*r | index), ascending index within a cell
     const int* big;              // n_big sphere indices, ascending
 };
@@ -865,7 +865,6 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 // spheres the geometric ray passes at a distance) take the exhaustive loop; rays with a non-finite component hit
 // nothing in the reference loop either (every t is NaN or infinite).
 // Spheres in `big` (padded box over too many cells) are tested for every ray.
-constexpr int kUnrollGrid = 1000;
 #ifndef RTM_GRID_K
 #define RTM_GRID_K 4
 #endif
@@ -925,9 +924,9 @@ struct GridWalk {
         tmz += az ? fabs(tdz) : 0.0;
         next_ok = (unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz;
         const unsigned cell = next_ok ? ((unsigned)iz * ny + iy) * nx + ix : 0u;
-        const unsigned* cs = G->cell_start;
-        nj = cs[cell];
-        nje = cs[cell + 1];
+        const uint2 range = G->cell_range[cell];
+        nj = range.x;
+        nje = range.y;
     }
     // Start the walk of (org, dir): the big list, the box, the guards.  Returns whether there is a walk to advance
     // (false: dis / best are final — a miss of the box, a non-finite ray, or the exhaustive loop has run).
@@ -995,10 +994,10 @@ struct GridWalk {
         t_exit = 0.0;
         next_ok = false;
         if (live) {
-            const unsigned* cs = G->cell_start;
             const unsigned cell = ((unsigned)iz * ny + iy) * nx + ix;
-            j = cs[cell];
-            jend = cs[cell + 1];
+            const uint2 range = G->cell_range[cell];
+            j = range.x;
+            jend = range.y;
             plan_next(G);  // (ix, iy, iz, tm* now describe the NEXT cell; t_exit is the current one's)
         }
         return live;
@@ -1015,17 +1014,19 @@ struct GridWalk {
             jend = nje;
             plan_next(G);
         }
-        // A lane with fewer records left than the batch reads on into the following lists (clamped to the table): testing
-        // a sphere that is not in the cell is harmless, the result is the minimum over ALL spheres.
-        const double4* recs = G->recs;
-        const unsigned last_rec = G->n_recs - 1u;
-        const unsigned left = jend - j;  // (0 for a lane in an empty cell: it still rides along, harmlessly)
+        // Up to kGridBatch of the cell's records, all loads first.  The loads and tests are per lane (a lane with two
+        // records left issues two loads): the walk is bound by the vector memory pipeline, which pays per lane and
+        // distinct line (profiles/r3/grid_variants.txt: the same loads issued twice cost +31 %, the tests' arithmetic
+        // twice +8 %), so nothing is fetched that is not needed.
+        const double4* recs = G->recs + j;
+        const unsigned left = jend - j;
         double4 r[kGridBatch];
 #pragma unroll
-        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) r[k] = recs[j + k < last_rec ? j + k : last_rec];
+        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k)
+            if (left > k) r[k] = recs[k];
 #pragma unroll
         for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
-            if (__builtin_amdgcn_ballot_w64(left > k) != 0) {
+            if (left > k) {
                 // the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
                 const unsigned long long w = (unsigned long long)__double_as_longlong(r[k].w);
                 double4 g = r[k];
@@ -1113,10 +1114,7 @@ __device__ __forceinline__ int nearest_hit_loop(const Scene& sc, const D3 org, c
 
 template <class M, int UNROLL, class Scene>
 __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
-    if constexpr (UNROLL == kUnrollGrid)
-        return nearest_hit_grid<M>(sc, org, dir, dis);
-    else
-        return nearest_hit_loop<M, UNROLL>(sc, org, dir, dis);
+    return nearest_hit_loop<M, UNROLL>(sc, org, dir, dis);
 }
 
 struct PathCounters {

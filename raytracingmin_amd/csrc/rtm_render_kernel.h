@@ -50,9 +50,9 @@ struct RenderParams {
     unsigned char* __restrict__ steal_ws;
     unsigned steal_rows, steal_depth;  // capacity in rows per tile; how far below the last sample a pixel may be stolen from
     unsigned magic_S, magic_SS;        // floor(2^32 / d) + 1: x / d == umulhi(x, magic) for x, d < 2^16 (a stolen sample's sub-pixel)
-    // grid kernel: blocks are dealt round-robin to the 8 XCDs, each with its own L2; with xcd_on, block b renders tile
-    // (b % 8) * xcd_q + min(b % 8, xcd_rem) + b / 8, so that an XCD's blocks cover one contiguous part of the frame and its
-    // L2 holds that part's cells (xcd_q = tiles / 8, xcd_rem = tiles % 8)
+    // grid kernel (rtm_grid_kernel.h): blocks are dealt round-robin to the 8 XCDs, each with its own L2; with xcd_on, block
+    // b of a launch renders its tile (b % 8) * xcd_q + min(b % 8, xcd_rem) + b / 8, so that an XCD's blocks cover one
+    // contiguous part of the frame and its L2 holds that part's cells (xcd_q = tiles / 8, xcd_rem = tiles % 8)
     unsigned xcd_on, xcd_q, xcd_rem;
 };
 constexpr size_t kTermRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned short);  // 1664 = 13 lines of 128 B
@@ -302,14 +302,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     auto pixel_xy = [&](int& px, int& py) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        unsigned tile = (SPLIT && blockIdx.x >= P.split_first)
-                            ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles : blockIdx.x;
-        if constexpr (UNROLL == kUnrollGrid) {
-            if (P.xcd_on) {
-                const unsigned xcd = tile & 7u;
-                tile = xcd * P.xcd_q + (xcd < P.xcd_rem ? xcd : P.xcd_rem) + (tile >> 3);
-            }
-        }
+        const unsigned tile = (SPLIT && blockIdx.x >= P.split_first)
+                                  ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles : blockIdx.x;
         const int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
         px = tx * 8 + (l & 7);
         py = band_row(P, ty, l >> 3);
@@ -868,27 +862,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
       }
     }
     unsigned long long st_near = 0, st_shade = 0, st_end = 0, st_iters = 0;
-    // Grid kernel: a lane's walk through the grid lives across the trips of this loop.  The walks of a wave's 64 rays end
-    // after very different numbers of cells (free paths are exponentially distributed: the longest of 64 is ~4x the
-    // mean), so the lanes are NOT shaded in lockstep: each trip advances the walks until at least kGridShadeAt8 / 8 of
-    // the wave's lanes have finished theirs, shades those — they start their next ray — and leaves the others walking.
-    [[maybe_unused]] GridWalk<M, Scene> walk;
-    [[maybe_unused]] bool walking = false;
     while (!DEFER && n < n_end) {
         D3 term;
         bool cont;
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-        if constexpr (UNROLL == kUnrollGrid && !STAMP) {
-            if (!walking) walking = walk.begin(sc, org, dir);
-            for (;;) {  // (wave-uniform: the counts are ballots over the lanes still in the render loop)
-                const unsigned in_loop = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                const unsigned on_walk = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking));
-                if (on_walk * 8u <= in_loop * (8u - (unsigned)kGridShadeAt8)) break;
-                if (walking) walking = walk.advance(sc, org, dir);
-            }
-            if (walking) continue;
-            cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
-        } else if constexpr (STAMP) {
+        if constexpr (STAMP) {
             ts0 = stamp_now();
             double dis;
             const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);

@@ -35,11 +35,13 @@ def rtm():
 
 def _variants(rtm, data, max_bounces):
     """Kernel variants that serve this scene: all of them, except that the labelled primary-hit-reuse row
-    (variant 15) is built for scenes of 1..24 spheres with a depth cap of at most 8."""
+    (variant 15) is built for scenes of 1..24 spheres with a depth cap of at most 8, and the uniform-grid kernel
+    (variant 17) needs a scene that gets a grid (257 gridded spheres or more: tests/test_grid_gpu.py asks for it by
+    name; variant 0 picks it from 512 spheres on)."""
     n = len(data.object)
     live = [v for v in range(rtm.lib().rtm_num_variants()) if not rtm.lib().rtm_variant_name(v).startswith(b"retired")]
     return [v for v in live
-            if v != 16 and (v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8))]  # 16: the fp32 row, not a parity path
+            if v not in (16, 17) and (v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8))]  # 16: the fp32 row, not a parity path
 
 
 def _probe(rtm, op, a, b=None):
@@ -1022,15 +1024,16 @@ def test_config4_band_parts_vs_oracle(rtm, oracle):
 
 
 def test_config5_full_frame_properties_and_spot_pixels(rtm, oracle):
-    """BASELINE configs[4]: 100 000 random spheres, 1920x1080 @ 256 spp, max 8 bounces — the full frame
-    through the large-scene pipeline (about 26 s of GPU): finite, non-negative, counter identities, and
+    """BASELINE configs[4]: 100 000 random spheres, 1920x1080 @ 256 spp, max 8 bounces — the full frame as
+    variant 0 renders it (the uniform-grid kernel, a quarter of a second; the exhaustive pipeline takes 24 s and is
+    compared with it on a strip in tests/test_grid_gpu.py): finite, non-negative, counter identities, and
     64 pixels spread over the frame against the oracle at the full 256 spp, bit for bit."""
     data = rtm.make_stress_scene(n=100_000, seed=12345)
     W, H = 1920, 1080
     data.width, data.height, data.samples, data.superSamples = W, H, 256, 1
     out, stats = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED).render_rows_device(want=("f64",))
     img = out["f64"].cpu().numpy()
-    assert stats["samples"] == W * H * 256 and stats["variant"] == 12
+    assert stats["samples"] == W * H * 256 and stats["variant"] == 17
     print(f"configs[4]: {stats['kernel_ms'] / 1e3:.1f} s, {stats['samples'] / stats['kernel_ms'] * 1e-3:.2f} Msamples/s, "
           f"{stats['casts'] / stats['samples']:.3f} casts/sample")
     assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() > 0.0
@@ -1506,15 +1509,15 @@ def test_scene_destroy_and_stream_release_do_not_wait_for_other_work(rtm, oracle
 
 
 def test_large_scene_render_only_enqueues(rtm, oracle):
-    """include/rtm.h: with a depth cap whose trip budget (spp x (max_bounces + 1)) is short enough, a render of a scene of
-    512 spheres or more — the two-launches-per-trip pipeline — only ENQUEUES, like every other size: the call returns
+    """include/rtm.h: with a depth cap whose trip budget (spp x (max_bounces + 1)) is short enough, a render through the
+    exhaustive large-scene pipeline (variant 12: two launches per trip) only ENQUEUES, like every other kernel: the call returns
     while the stream is still busy, a second frame queued behind it is the same frame, and both are the frame of the
     blocking call (which follows the device's count instead) and of the oracle on spot pixels."""
     import time
     import torch
     data = rtm.make_stress_scene(n=100_000, seed=12345)
     data.width, data.height, data.samples, data.superSamples = 256, 144, 8, 1
-    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=77)
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=77, variant=12)
     blocking, st = r.render_rows_device(want=("f64",), stats=True)            # also warms scene + buffers
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1537,7 +1540,7 @@ def test_large_scene_render_only_enqueues(rtm, oracle):
     for k, (x, y) in enumerate(px):
         assert _bits_equal(got[y, x], ref[k]), (x, y)
     # unlimited depth: no budget can be known, the call follows the count (blocks) — and is still the oracle's frame
-    ru = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=77)
+    ru = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=77, variant=12)
     u, _ = ru.render_rows_device(0, 16, want=("f64",), stats=False)
     refu, _ = oracle.render_pixels(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=77, height=144),
                                    np.array([[5, 3], [200, 9]]))
