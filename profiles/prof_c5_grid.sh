@@ -25,16 +25,21 @@ def per_launch(d, match):
         for k,v in agg.items(): res[k]=v/max(1,disp)
     return res
 for d in ('sq','l2','fetch','write','mix'):
-    out.update(per_launch(d, lambda n: 'render_tiles' in n))
+    out.update(per_launch(d, lambda n: 'render_grid' in n))
+for d in ('fetch','write'):
+    for k,v in per_launch(d, lambda n: 'grid_finalize' in n).items(): out['grid_finalize.'+k]=v
 stats=[r for f in glob.glob('$O/trace/*/*_kernel_stats.csv') for r in csv.DictReader(open(f))]
-out['kernel_stats']=[r for r in stats if 'render' in r['Name']]
+out['kernel_stats']=[r for r in stats if 'render' in r['Name'] or 'grid' in r['Name']]
+clk=out.get('GRBM_GUI_ACTIVE',0)
 try:
-    out['valu_busy']=out['SQ_ACTIVE_INST_VALU']*4/1024/out['GRBM_GUI_ACTIVE']
+    ns=float([r for r in out['kernel_stats'] if 'render_grid' in r['Name']][0]['AverageNs'])
+    out['valu_busy_at_2.4GHz']=out['SQ_ACTIVE_INST_VALU']*4/1024/(ns*2.4)  # (GRBM_GUI_ACTIVE comes out summed over the 8 XCDs here)
+    out['active_lanes_frac']=out['SQ_THREAD_CYCLES_VALU']/(out['SQ_ACTIVE_INST_VALU']*64)
     out['wave_wait_any_share']=out['SQ_WAIT_ANY']/out['SQ_WAVE_CYCLES']
     out['wave_wait_inst_share']=out['SQ_WAIT_INST_ANY']/out['SQ_WAVE_CYCLES']
     out['l2_hit_rate']=out['TCC_HIT_sum']/(out['TCC_HIT_sum']+out['TCC_MISS_sum'])
 except Exception as e:
     out['derived_error']=repr(e)
-out['_note']='per launch, C5 full frame, grid kernel (variant 17); FETCH_SIZE/WRITE_SIZE in KB as the counters report them'
+out['_note']='per launch, C5 full frame, render_grid_kernel (variant 17) and, prefixed, grid_finalize_kernel; FETCH_SIZE/WRITE_SIZE in KB as the counters report them'
 json.dump(out,open('$O/summary.json','w'),indent=1); print(json.dumps(out,indent=1))
 PY

@@ -31,8 +31,19 @@ for d in ('fetch','write','mix','mix2','mix3'):
     out.update(per_launch(d, lambda n: 'render_tiles' in n))
 for d in ('fetch','write'):
     for k,v in per_launch(d, lambda n: 'split_finalize' in n).items(): out['split_finalize.'+k]=v
+    for k,v in per_launch(d, lambda n: 'steal_finalize' in n).items(): out['steal_finalize.'+k]=v
 stats=[r for f in glob.glob('$O/trace/*/*_kernel_stats.csv') for r in csv.DictReader(open(f))]
-out['kernel_stats']=[r for r in stats if 'render' in r['Name'] or 'split' in r['Name']]
+out['kernel_stats']=[r for r in stats if 'render' in r['Name'] or 'split' in r['Name'] or 'steal' in r['Name']]
+try:  # the figure bench.py replays as roofline.traffic (profiles/latest_traffic.json)
+    kb=lambda k: out.get(k,0.0)
+    tr={'render_fetch_kb':kb('FETCH_SIZE'),'render_write_kb':kb('WRITE_SIZE'),
+        'split_finalize_fetch_kb':kb('split_finalize.FETCH_SIZE'),'split_finalize_write_kb':kb('split_finalize.WRITE_SIZE'),
+        'steal_finalize_fetch_kb':kb('steal_finalize.FETCH_SIZE'),'steal_finalize_write_kb':kb('steal_finalize.WRITE_SIZE')}
+    tr['bytes_per_launch']=1024.0*sum(tr.values())
+    tr['bytes_per_launch_with_wide_reads_doubled']=tr['bytes_per_launch']+1024.0*(tr['split_finalize_fetch_kb']+tr['steal_finalize_fetch_kb'])
+    json.dump(tr,open('$O/traffic.json','w'),indent=1)
+except Exception as e:
+    out['traffic_error']=repr(e)
 out['_note']='per launch, headline frame, default kernel; FETCH_SIZE/WRITE_SIZE in KB as the counters report them (x 1024 = bytes)'
 json.dump(out,open('$O/summary.json','w'),indent=1); print(json.dumps(out,indent=1))
 PY

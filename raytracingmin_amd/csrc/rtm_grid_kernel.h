@@ -15,9 +15,10 @@
 //     path and take the next unit) and leaves the others walking.
 //   * the sum over a pixel's samples must be added in sample order (src/Renderer.cpp:241-242; fp64 addition does not
 //     commute bitwise), and the samples of a pixel now finish on different lanes in any order: every sample's term
-//     (cal / SS / SS / S, clamped — :240) goes to memory, [tile][sample][pixel][3] doubles, and grid_finalize_kernel
-//     adds them per pixel in sample order and stores the pixel.  24 bytes per sample written once and read once,
-//     coalesced on the read side: 25 GB for the 5.3e8 samples of BASELINE configs[4], 3 % of the frame's time.
+//     (cal / SS / SS / S, clamped — :240) goes to memory, [tile][sample][pixel] slots of 32 bytes, and
+//     grid_finalize_kernel adds them per pixel in sample order and stores the pixel.  A sector per sample written once
+//     and read once, coalesced on the read side: 2 x 17 GB for the 5.3e8 samples of BASELINE configs[4], 1 % of the
+//     frame's time in the finalize.
 #ifndef RTM_GRID_KERNEL_H
 #define RTM_GRID_KERNEL_H
 
@@ -29,7 +30,11 @@ namespace rtm {
 #define RTM_GRID_WPE 4
 #endif
 constexpr int kGridWavesPerSimd = RTM_GRID_WPE;  // launch bound of the grid kernel (profiles/r3/grid_variants.txt)
-__host__ __device__ inline size_t grid_tile_term_bytes(unsigned total_samples) { return (size_t)total_samples * 64 * 3 * sizeof(double); }
+// a term's slot: three doubles padded to 32 bytes — one aligned 32-byte sector, written whole by two 16-byte stores (24-byte
+// slots straddle sectors: L2 then FETCHES around every store, 55 GB per configs[4] frame, profiles/r3/README.md)
+constexpr int kGridTermDoubles = 4;
+typedef double grid_dbl2 __attribute__((ext_vector_type(2)));
+__host__ __device__ inline size_t grid_tile_term_bytes(unsigned total_samples) { return (size_t)total_samples * 64 * kGridTermDoubles * sizeof(double); }
 
 // tile of block b: blocks are dealt round-robin to the 8 XCDs, each with its own L2 (RenderParams::xcd_on)
 __device__ __forceinline__ unsigned grid_tile_of_block(const RenderParams& P, unsigned b) {
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     const unsigned tile = tile_base + local_tile;
     const int tile_x8 = (int)(tile % (unsigned)P.tiles_x) * 8, tile_y = (int)(tile / (unsigned)P.tiles_x);
     const unsigned total_units = P.total_samples * 64u;
-    double* const terms = reinterpret_cast<double*>(P.contrib) + (size_t)local_tile * P.total_samples * 192;
+    double* const terms = reinterpret_cast<double*>(P.contrib) + (size_t)local_tile * P.total_samples * (64 * kGridTermDoubles);
 
     PathCounters pc = {0, 0, 0};
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
@@ -124,10 +129,10 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
                 // :240 cal / SS / SS / S (power-of-two divisors as exact multiplications), :241 the clamp
                 const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
                 const D3 add = clamp01_d3(cal);
-                double* t = terms + (size_t)unit * 3;  // unit = sample * 64 + pixel
-                __builtin_nontemporal_store(add.x, t);
-                __builtin_nontemporal_store(add.y, t + 1);
-                __builtin_nontemporal_store(add.z, t + 2);
+                grid_dbl2* t = reinterpret_cast<grid_dbl2*>(terms + (size_t)unit * kGridTermDoubles);  // unit = sample * 64 + pixel
+                const grid_dbl2 lo = {add.x, add.y}, hi = {add.z, 0.0};
+                __builtin_nontemporal_store(lo, t);
+                __builtin_nontemporal_store(hi, t + 1);
                 busy = take_unit();
             }
         }
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
 }
 
 // image[pixel] = ((0 + term[0]) + term[1]) + ... in sample order (src/Renderer.cpp:241-248).  One wave per tile, lane =
-// pixel; a sample's 64 terms are one contiguous 1 536-byte row.
+// pixel; a sample's 64 terms are one contiguous 2 048-byte row.
 __global__ __launch_bounds__(64) void grid_finalize_kernel(const RenderParams P, const unsigned tile_base) {
     const int lane = threadIdx.x;
     const unsigned tile = tile_base + blockIdx.x;
@@ -149,21 +154,23 @@ __global__ __launch_bounds__(64) void grid_finalize_kernel(const RenderParams P,
     const int py = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);
     const bool valid = px < P.W && py < P.row_end;
     if (!valid) return;  // (its units were never traced: the rows hold nothing for it)
-    const double* t = reinterpret_cast<const double*>(P.contrib) + (size_t)blockIdx.x * P.total_samples * 192 + lane * 3;
+    constexpr int kRow = 64 * kGridTermDoubles;  // doubles per sample row
+    const double* t = reinterpret_cast<const double*>(P.contrib) + (size_t)blockIdx.x * P.total_samples * kRow + lane * kGridTermDoubles;
     D3 acc = d3(0, 0, 0);
     unsigned s = 0;
     for (; s + 4 <= P.total_samples; s += 4) {  // four rows in flight; the additions stay in order
         D3 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double* r = t + (size_t)(s + k) * 192;
-            v[k] = d3(__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + 1), __builtin_nontemporal_load(r + 2));
+            const grid_dbl2* r = reinterpret_cast<const grid_dbl2*>(t + (size_t)(s + k) * kRow);
+            const grid_dbl2 lo = __builtin_nontemporal_load(r), hi = __builtin_nontemporal_load(r + 1);
+            v[k] = d3(lo.x, lo.y, hi.x);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = acc + v[k];
     }
     for (; s < P.total_samples; ++s) {
-        const double* r = t + (size_t)s * 192;
+        const double* r = t + (size_t)s * kRow;
         acc = acc + d3(r[0], r[1], r[2]);
     }
     store_pixel(P, true, px, py, acc);

@@ -1539,7 +1539,7 @@ int stream_status(int device, void* stream_v) {
 // The render proper: `view` is resident on opt->device and stays valid until the queued work has run.
 // The caller holds g_gate (shared).
 // Variant 17 (rtm_grid_kernel.h): the render kernel leaves every sample's term in the stream's term buffer, the finalize
-// kernel adds them per pixel in sample order.  The buffer holds tiles x spp x 1 536 bytes (12.7 GB for the 32 400 tiles of
+// kernel adds them per pixel in sample order.  The buffer holds tiles x spp x 2 048 bytes (17.0 GB for the 32 400 tiles of
 // a 1080p frame at 256 spp): beyond kGridTermBudget — or what the device will give — the frame is rendered in several
 // launches of as many tiles as fit, one behind the other on the stream, each followed by its finalize.
 constexpr size_t kGridTermBudget = (size_t)16 << 30;

@@ -946,9 +946,22 @@ struct GridWalk {
         // the ray's parameter interval inside the grid's box
         double t0 = 0.0, t_out = DBL_MAX;
         const double inf = __builtin_huge_val();
+        // 1 / d for the walk's set-up: v_rcp_f64 + two Newton steps (2^-52 relative; the compiler's correctly rounded
+        // division is three times the instructions, and nothing here needs the last bit: the pads have ten orders of
+        // magnitude of room), the true division where the exponent is extreme
+        const bool tame = M::moderate(dir.x) && M::moderate(dir.y) && M::moderate(dir.z);
+        const bool slow_div = __builtin_amdgcn_ballot_w64(!tame) != 0;
         auto slab = [&](const double o, const double d, const double lo, const double hi, double& inv) {
             const bool flat = d == 0.0;
-            inv = 1.0 / d;
+            if (slow_div) {
+                inv = 1.0 / d;
+            } else {
+                double r = __builtin_amdgcn_rcp(d);
+                double e = __builtin_fma(-d, r, 1.0);
+                r = __builtin_fma(r, e, r);
+                e = __builtin_fma(-d, r, 1.0);
+                inv = __builtin_fma(r, e, r);
+            }
             const double ta = (lo - o) * inv, tb = (hi - o) * inv;
             const double tn = flat ? ((o >= lo && o <= hi) ? -inf : inf) : (ta < tb ? ta : tb);
             const double tf = flat ? inf : (ta < tb ? tb : ta);
