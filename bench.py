@@ -246,11 +246,13 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False):
         if os.path.exists(gpath):
             gj = json.load(open(gpath))
             if "FETCH_SIZE" in gj and "WRITE_SIZE" in gj:
-                row["traffic"] = (gj["FETCH_SIZE"] + gj["WRITE_SIZE"]) * 1024.0
+                row["traffic"] = 1024.0 * sum(gj.get(k, 0.0) for k in ("FETCH_SIZE", "WRITE_SIZE", "grid_finalize.FETCH_SIZE",
+                                                                        "grid_finalize.WRITE_SIZE"))
                 row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_grid_pmc_summary.json",
-                                         "note": "FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 --pmc, separate passes; "
-                                                 "profiles/prof_c5_grid.sh): L2 misses of the 22 MB cell lists, served "
-                                                 "mostly by the Infinity Cache"}
+                                         "note": "FETCH_SIZE + WRITE_SIZE per frame, render_grid_kernel + grid_finalize_kernel "
+                                                 "(rocprofv3 --pmc, separate passes; profiles/prof_c5_grid.sh): the per-sample "
+                                                 "terms written once and read once (2 x 17 GB) and the L2 misses of the 22 MB "
+                                                 "of cell lists, served mostly by the Infinity Cache"}
         out["c5_stress_100k_full_1080p_256spp"] = row
 
         # the exhaustive large-scene pipeline (variant 12: every cast tests all 100 000 spheres, packed-fp32 rejection
