@@ -175,11 +175,12 @@ int rtm_stream_release(int device, void* stream);
  * rtm_scene_create flattens `spheres` (HOST pointer, or a DEVICE pointer on `device` when
  * spheres_on_device != 0) and uploads the tables; it returns when they are resident, so the caller's
  * array may be freed at once.  A scene belongs to one device.
- * For an all-sphere scene of 257 spheres or more the call also builds, on the host (~40 ms per 100 000 spheres), a
- * uniform grid over the spheres (~32 B x 6 per sphere + 8 B per cell, ~2 cells per sphere): renders of 512 spheres or
- * more then find the reference loop's nearest hit (src/Renderer.cpp:58-73: same object, same distance, same image)
- * through the grid instead of testing every sphere for every cast (rtm_options.variant 17; variant 0 picks it when
- * the camera is within about two scene diagonals of the scene, variant 12 is the exhaustive pipeline). */
+ * For an all-sphere scene of 64 spheres or more (not counting those that span the scene, like the Cornell walls) the
+ * call also builds, on the host (~40 ms per 100 000 spheres), a uniform grid over the spheres (~32 B x 6 per sphere +
+ * 8 B per cell, ~2 cells per sphere): renders then find the reference loop's nearest hit (src/Renderer.cpp:58-73:
+ * same object, same distance, same image) through the grid instead of testing every sphere for every cast
+ * (rtm_options.variant 17; variant 0 picks it when the camera is within about two scene diagonals of the scene;
+ * variants 3 / 14 and, from 512 spheres, 12 are the exhaustive kernels). */
 int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
                      rtm_scene** out_scene);
 /* The same for a list of objects of any type (spheres and planes in the reference's vector order, which
@@ -200,8 +201,8 @@ size_t rtm_scene_size(const rtm_scene* scene);
  * rtm_render_scene with stats == NULL only ENQUEUES work on `stream` and returns: no copy from pageable
  * memory and no wait — except that the FIRST call on a (device, stream) pair sets up its context, and a call
  * that needs a larger work buffer than the pair has (see rtm_release_scratch) grows it, which allocates and
- * waits for that stream's queued work once; steady-state calls do neither.  Scenes of 512 spheres or more that have
- * a grid (rtm_scene_create) are two launches per frame like any other; without one — rtm_render_device on a device
+ * waits for that stream's queued work once; steady-state calls do neither.  Scenes that have a grid
+ * (rtm_scene_create) are two launches per frame like any other; scenes of 512 spheres or more without one — rtm_render_device on a device
  * array, scenes the grid declines (planes, non-finite geometry), a far-away camera, variant 12 by name — they run a
  * pipeline of two launches per ray cast of the slowest pixel: with a depth cap such that samples x superSamples^2 x
  * (max_bounces + 1) <= 16 384 every trip that could be needed is enqueued at once (those after the last active pixel

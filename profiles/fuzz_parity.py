@@ -69,8 +69,8 @@ for case in range(cases):
         data.width, data.height = int(rng.integers(1, 40)), int(rng.integers(1, 24))
         data.samples, data.superSamples = int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2]))
     variant = int(rng.choice([0, 0, 0, 2, 9, 14, 3, 12]))
-    if n >= 300 and case % 2 == 0:
-        variant = 17  # the uniform-grid kernel by name (variant 0 picks it from 512 spheres on)
+    if n >= 100 and case % 2 == 0:
+        variant = 17  # the uniform-grid kernel by name (variant 0 picks it whenever the scene has a grid: 64 gridded spheres)
     if case % 7 == 3 and 1 <= n <= 24 and 0 <= mb <= 8 and mode == "repaired":
         variant = 15  # the labelled primary-hit-reuse row must give the same bits where it applies
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED

@@ -297,8 +297,12 @@ static SceneView scene_view(const double* geom, const double* mat, const double*
 // Built on the host from the flattened geometry rows (cx, cy, cz, float r*r) when a scene OBJECT is created: a few
 // milliseconds for 100 000 spheres, once per scene.  ~kGridCellsPerSphere cells per sphere; a sphere whose padded box
 // covers more than kGridBigCells cells goes to the list every ray tests.  No grid (the other kernels serve the scene)
-// for fewer than kGridMinSpheres spheres, non-finite geometry, more than kGridMaxBig big spheres or planes.
-constexpr size_t kGridMinSpheres = 257;  // (ids beyond a byte: the grid kernel is instantiated for u32 records only)
+// for fewer than kGridMinSpheres gridded spheres (below that the packed-record kernels are as fast or faster:
+// profiles/r3/grid_crossover.txt), non-finite geometry, more than kGridMaxBig big spheres or planes.
+#ifndef RTM_GRID_MIN
+#define RTM_GRID_MIN 64
+#endif
+constexpr size_t kGridMinSpheres = RTM_GRID_MIN;  // gridded spheres a scene needs to get a grid (profiles/r3/grid_crossover.txt)
 constexpr int kGridBigCells = 125, kGridMaxBig = 1024, kGridMaxDim = 1024;
 constexpr double kGridDdTol = 4e-7;  // |dir.dir - 1| the pads cover: twice what the reference's float-sqrt Normalize leaves (1.8e-7)
 static double grid_cells_per_sphere() {
@@ -1623,11 +1627,12 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         return RTM_ERR_UNSUPPORTED;
     }
     if (variant == kVariantAuto)
-        variant = n <= (size_t)kAutoLdsTableSpheres ? kVariantFastLds : n < 256 ? kVariantGlobalDefer :
-                  n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal :
-                  view.grid != nullptr ? kVariantGrid : kVariantWavefrontRejectF32;
+        variant = n <= (size_t)kAutoLdsTableSpheres ? kVariantFastLds :
+                  view.grid != nullptr ? kVariantGrid :  // (grid_for: the scene has one and the camera is within its reach)
+                  n < 256 ? kVariantGlobalDefer :
+                  n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
     if (variant == kVariantGrid && view.grid == nullptr) {
-        set_last_error("variant 17 (uniform grid) serves all-sphere scenes of 257 spheres or more held by an rtm_scene "
+        set_last_error("variant 17 (uniform grid) serves all-sphere scenes of 64 gridded spheres or more held by an rtm_scene "
                        "(rtm_scene_create*, rtm_render_rows*); this scene has no grid");
         return RTM_ERR_UNSUPPORTED;
     }
@@ -2182,7 +2187,7 @@ int grid_nearest_probe(const rtm_sphere* sp, size_t n, const double* org, const 
     int rc = scene_build_host(ds, sp, n, device);
     if (rc != RTM_OK) return rc;
     if (!ds.grid.p) {
-        set_last_error("this scene gets no grid (fewer than 257 gridded spheres, non-finite geometry, or too many spheres "
+        set_last_error("this scene gets no grid (fewer than 64 gridded spheres, non-finite geometry, or too many spheres "
                        "that span the scene)");
         return RTM_ERR_UNSUPPORTED;
     }

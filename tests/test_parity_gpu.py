@@ -36,8 +36,8 @@ def rtm():
 def _variants(rtm, data, max_bounces):
     """Kernel variants that serve this scene: all of them, except that the labelled primary-hit-reuse row
     (variant 15) is built for scenes of 1..24 spheres with a depth cap of at most 8, and the uniform-grid kernel
-    (variant 17) needs a scene that gets a grid (257 gridded spheres or more: tests/test_grid_gpu.py asks for it by
-    name; variant 0 picks it from 512 spheres on)."""
+    (variant 17) needs a scene that gets a grid (64 gridded spheres or more: tests/test_grid_gpu.py asks for it by
+    name; variant 0 picks it for every scene that has one)."""
     n = len(data.object)
     live = [v for v in range(rtm.lib().rtm_num_variants()) if not rtm.lib().rtm_variant_name(v).startswith(b"retired")]
     return [v for v in live
@@ -729,7 +729,8 @@ def test_auto_variant_by_scene_size(rtm, oracle, n):
 @pytest.mark.parametrize("n", [255, 256, 257])
 def test_record_packing_boundary(rtm, oracle, n):
     """Hit ids and the identity index share a byte in the packed records: 255 spheres is the last scene
-    that fits, 256 must take the LDS record stack, 257 the large-scene pipeline — all the same image."""
+    that fits, 256 must take the LDS record stack, 257 four-byte records — all the same image (variant 0 takes the
+    uniform grid at these sizes; the exhaustive kernels are asked for by name)."""
     data = rtm.make_stress_scene(n, seed=3)
     data.width, data.height, data.samples, data.superSamples = 48, 32, 4, 2
     # pull the camera close so that high-index spheres are hit, too
