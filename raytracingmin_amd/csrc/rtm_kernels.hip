@@ -1552,8 +1552,12 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx) {
         const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
         return e && e[0] == '0';
     }();
+    static const size_t budget = [] {
+        const char* e = std::getenv("RTM_DEBUG_GRID_BUDGET_MB");  // test knob: the term buffer's budget in MiB (several launches per frame)
+        return e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : kGridTermBudget;
+    }();
     const size_t per_tile = grid_tile_term_bytes(P.total_samples);
-    size_t chunk = std::min<size_t>(tiles, std::max<size_t>(1, kGridTermBudget / per_tile));
+    size_t chunk = std::min<size_t>(tiles, std::max<size_t>(1, budget / per_tile));
     void* ws = nullptr;
     for (;;) {
         if (scratch_acquire(ctx, kScratchTerms, chunk * per_tile, &ws) == RTM_OK) break;

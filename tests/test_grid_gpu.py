@@ -273,3 +273,51 @@ def test_config5_strip_grid_vs_pipeline_and_spot_pixels(rtm, oracle):
     ost, oarr, n = _oracle_view(oracle, data)
     ref, _ = oracle.render_pixels(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=0x5EED, height=H), xy)
     assert np.array_equal(g["f64"][xy[:, 1] - rows[0], xy[:, 0]].view(np.uint64), ref.view(np.uint64))
+
+
+def test_grid_camera_out_of_reach_and_chunked_term_buffer(rtm, oracle):
+    """(1) A camera farther from the scene than the grid's pads were sized for: variant 0 leaves the grid alone, variant 17
+    by name sends those primary rays through its exhaustive loop — the oracle's frame either way.  (2) A term buffer too
+    small for the frame (RTM_DEBUG_GRID_BUDGET_MB, read once per process: a child process): the frame is rendered in
+    several launches of a few tiles each — the same frame."""
+    import os
+    import subprocess
+    import sys
+    data = rtm.make_stress_scene(n=300, seed=5)
+    data.width, data.height, data.samples, data.superSamples = 40, 24, 4, 1
+    data.camera.origin = rtm.vec3(0.0, 0.0, -5000.0)
+    data.camera.fov = 0.02
+    ost, oarr, n = _oracle_view(oracle, data)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=11, height=24))
+    assert ref.any()
+    auto, st0 = _image(rtm, data, "repaired", 8, 11, 0)
+    named, st17 = _image(rtm, data, "repaired", 8, 11, 17)
+    assert st0["variant"] != 17 and st17["variant"] == 17
+    assert np.array_equal(auto["f64"].view(np.uint64), ref.view(np.uint64))
+    assert np.array_equal(named["f64"].view(np.uint64), ref.view(np.uint64)) and st17["casts"] == cnt["casts"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import raytracingmin_amd as rtm
+data = rtm.make_stress_scene(n=2000, seed=9)
+data.width, data.height, data.samples, data.superSamples = 200, 120, 8, 2
+r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3, variant=17)
+out, st = r.render_rows(0, 120, want=("f64",))
+np.save(sys.argv[1], out["f64"])
+print(st["casts"])
+"""
+    frames, casts = [], []
+    for budget in ("1", ""):  # 1 MiB: 8 tiles of 32 spp per launch, 47 launches; default: one
+        env = dict(os.environ)
+        env.pop("RTM_DEBUG_GRID_BUDGET_MB", None)
+        if budget:
+            env["RTM_DEBUG_GRID_BUDGET_MB"] = budget
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grid_chunk_{budget or 'whole'}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        frames.append(np.load(path))
+        casts.append(int(r.stdout.strip().splitlines()[-1]))
+        os.remove(path)
+    assert np.array_equal(frames[0].view(np.uint64), frames[1].view(np.uint64)) and casts[0] == casts[1]
