@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
             if (walking) walking = walk.advance(sc, org, dir);
         }
         if (busy && !walking) {
+            RTM_GRID_OCC(8);
             D3 term;
             bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
             if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
                 depth = 0;
             }
             if (!cont) {
+                RTM_GRID_OCC(9);
                 const bool deep = depth > LDS_D;
                 const D3 L = (__builtin_amdgcn_ballot_w64(deep) == 0)
                                  ? path_fold_blocked(sc, term, depth, [&](int d) { return (int)rec[d * 64 + lane]; })
@@ -150,6 +152,18 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
 __global__ __launch_bounds__(64) void grid_finalize_kernel(const RenderParams P, const unsigned tile_base) {
     const int lane = threadIdx.x;
     const unsigned tile = tile_base + blockIdx.x;
+#ifdef RTM_GRID_EXP_OCC
+    if (blockIdx.x == 0 && lane == 0) {
+        const char* names[10] = {"begin", "advance", "step", "test0", "test1", "test2", "test3", "sqrt", "shade", "path end"};
+        for (int r = 0; r < 10; ++r) {
+            // (one value per call: device printf mangled three 64-bit arguments in one)
+            printf("[grid occ] %s:", names[r]);
+            printf(" executions %llu", g_grid_occ[2 * r]);
+            printf(" lanes %llu\n", g_grid_occ[2 * r + 1]);
+            g_grid_occ[2 * r] = g_grid_occ[2 * r + 1] = 0ull;
+        }
+    }
+#endif
     const int px = (int)(tile % (unsigned)P.tiles_x) * 8 + (lane & 7);
     const int py = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);
     const bool valid = px < P.W && py < P.row_end;

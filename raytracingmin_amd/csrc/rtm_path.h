@@ -874,6 +874,22 @@ constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the wal
 #endif
 constexpr int kGridShadeAt8 = RTM_GRID_SHADE_AT;  // the render loop shades when this many eighths of a wave's lanes have finished their walks
 
+// EXPERIMENT build (-DRTM_GRID_EXP_OCC): how often each region of the grid kernel runs and with how many lanes
+// (profiles/r3/grid_occupancy.txt); the counters are printed and cleared by grid_finalize_kernel.
+#ifdef RTM_GRID_EXP_OCC
+__device__ unsigned long long g_grid_occ[32];
+#define RTM_GRID_OCC(region)                                                                          \
+    do {                                                                                              \
+        const unsigned long long occ_m = __builtin_amdgcn_ballot_w64(true);                           \
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(occ_m)) {                                      \
+            atomicAdd(&g_grid_occ[2 * (region)], 1ull);                                               \
+            atomicAdd(&g_grid_occ[2 * (region) + 1], (unsigned long long)__builtin_popcountll(occ_m)); \
+        }                                                                                             \
+    } while (0)
+#else
+#define RTM_GRID_OCC(region) do { } while (0)
+#endif
+
 // One ray's walk through the grid, as per-lane state that can be advanced a trip at a time: the render kernel's lanes
 // walk independently and are shaded in groups (rtm_render_kernel.h), the probe and the plain nearest_hit run it to the end.
 template <class M, class Scene, bool COUNT = false>
@@ -902,6 +918,7 @@ struct GridWalk {
         const double b = dot(p_o, dir);                            // :199
         const double D4 = b * b - dot(p_o, p_o) + g.w;             // :200
         if (D4 >= 0.0) {                                           // :202 (a NaN D4 ends in a NaN t: never accepted)
+            RTM_GRID_OCC(7);
             const double sq = M::sqrt64(D4);
             const double t1 = b - sq, t2 = b + sq;
             const double t = (t1 > 0.001) ? t1 : t2;  // :212-223; accepted as in sphere_update, ties to the lower index
@@ -932,6 +949,7 @@ struct GridWalk {
     // (false: dis / best are final — a miss of the box, a non-finite ray, or the exhaustive loop has run).
     __device__ __forceinline__ bool begin(const Scene& sc, const D3 org, const D3 dir) {
         HdrPtr G = header(sc);
+        RTM_GRID_OCC(0);
         best = -1;
         dis = DBL_MAX;
         if constexpr (COUNT) tests = steps = 0;
@@ -1019,7 +1037,9 @@ struct GridWalk {
     // Returns whether the walk goes on (false: dis / best are final).
     __device__ __forceinline__ bool advance(const Scene& sc, const D3 org, const D3 dir) {
         HdrPtr G = header(sc);
+        RTM_GRID_OCC(1);
         if (j >= jend) {
+            RTM_GRID_OCC(2);
             // this cell is done: every sphere that can be hit before its exit has been tested (see above)
             if (dis <= t_exit || !next_ok) return false;
             if constexpr (COUNT) ++steps;
@@ -1040,6 +1060,7 @@ struct GridWalk {
 #pragma unroll
         for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
             if (left > k) {
+                RTM_GRID_OCC(3 + k);
                 // the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
                 const unsigned long long w = (unsigned long long)__double_as_longlong(r[k].w);
                 double4 g = r[k];
