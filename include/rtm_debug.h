@@ -37,6 +37,14 @@ int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, doubl
  * ray, dim x, dim y, dim z}.  RTM_ERR_UNSUPPORTED when the scene gets no grid. */
 int rtm_debug_grid_nearest(const rtm_sphere* spheres, size_t n, const double* org, const double* dir, size_t n_rays,
                            int32_t* out_id, double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info);
+/* The grid's builder alone, on the HOST (no device is touched; runs in the CPU test suite): info[12] = {cells, list
+ * entries, spheres tested by every ray, dim x, y, z} followed by the bit patterns of six doubles {box lo x, y, z, cell edge,
+ * reach of origins from the box's centre, largest hit parameter the pads cover}; pads[n]: every sphere's pad; and, where the
+ * pointers are not NULL, ranges[2 x cells] (first, one past last entry of each cell's list; x fastest), items[entries]
+ * (sphere indices, ascending within a cell) and big[...].  RTM_ERR_UNSUPPORTED: no grid; RTM_ERR_CAPACITY: a buffer is short
+ * (info is filled: call once without buffers for the sizes). */
+int rtm_debug_grid_build(const rtm_sphere* spheres, size_t n, uint64_t* info, double* pads, uint32_t* ranges, size_t ranges_cap,
+                         uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */
 int rtm_debug_component_bench(int which, const rtm_sphere* spheres, size_t n, int reps, int blocks, int lds_pad,
                               double* cycles_per_rep);

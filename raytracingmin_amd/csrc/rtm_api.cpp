@@ -121,6 +121,10 @@ int rtm_debug_grid_nearest(const rtm_sphere* sp, size_t n, const double* org, co
                            int32_t* out_id, double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info) {
     RTM_GUARD(rtm::grid_nearest_probe(sp, n, org, dir, n_rays, out_id, out_t, out_tests, out_steps, info))
 }
+int rtm_debug_grid_build(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads, uint32_t* ranges, size_t ranges_cap,
+                         uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap) {
+    RTM_GUARD(rtm::grid_build_host(sp, n, info, pads, ranges, ranges_cap, items, items_cap, big, big_cap))
+}
 int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms) {
     RTM_GUARD(rtm::fp64_peak(waves_per_simd, min_ms, tflops, kernel_ms))
 }

@@ -319,7 +319,7 @@ struct GridBuild {
     size_t refs = 0;  // entries of `items` that are real (items holds one dummy when there is none)
 };
 static bool n_refs_valid(const GridBuild& B) { return B.refs != 0; }
-static bool make_grid(const double* g, size_t n, GridBuild& out) {
+static bool make_grid(const double* g, size_t n, GridBuild& out, double* pads_out = nullptr) {
     const double lambda = grid_cells_per_sphere();
     if (n < kGridMinSpheres || n >= (1u << 29) || !(lambda > 0.0)) return false;
     std::vector<double> R(n), pad(n);
@@ -388,6 +388,7 @@ static bool make_grid(const double* g, size_t n, GridBuild& out) {
             hi[k] = std::max(hi[k], g[i * 4 + k] + R[i] + pad[i]);
         }
     }
+    if (pads_out) std::memcpy(pads_out, pad.data(), n * sizeof(double));
     GridHeader& H = out.hdr;
     std::memset(&H, 0, sizeof H);
     size_t cells = 1;
@@ -462,6 +463,38 @@ static bool make_grid(const double* g, size_t n, GridBuild& out) {
     }
     return true;
 }
+// rtm_debug_grid_build: the builder alone, on the HOST (no device is touched) — what tests/test_host_io.py checks the
+// lists' invariants on.  info[12] = {cells, records, big, dim x, y, z} then, as doubles' bit patterns, {lo x, y, z, h, reach,
+// t_ok}; pads: n doubles (a big sphere's is its pad too); with buffers, ranges: 2 x cells unsigned, items: `records` sphere
+// indices, big: `big` sphere indices.  RTM_ERR_UNSUPPORTED when the scene gets no grid, RTM_ERR_CAPACITY when a buffer is short.
+int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads, uint32_t* ranges, size_t ranges_cap,
+                    uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap) {
+    if (!sp || !n || !info) return RTM_ERR_INVALID_ARGUMENT;
+    std::vector<double> hg, hm;
+    flatten_scene(sp, n, hg, hm);
+    GridBuild B;
+    if (!make_grid(hg.data(), n, B, pads)) {
+        set_last_error("this scene gets no grid");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    const size_t cells = B.cell_start.size() - 1;
+    info[0] = cells;
+    info[1] = B.refs;
+    info[2] = B.big.size();
+    for (int k = 0; k < 3; ++k) info[3 + k] = (uint64_t)B.hdr.dim[k];
+    const double d[6] = {B.hdr.lo[0], B.hdr.lo[1], B.hdr.lo[2], B.hdr.h, std::sqrt(B.hdr.reach2), B.hdr.t_ok};
+    std::memcpy(info + 6, d, sizeof d);
+    if ((ranges && ranges_cap < cells * 2) || (items && items_cap < B.refs) || (big && big_cap < B.big.size())) return RTM_ERR_CAPACITY;
+    if (ranges)
+        for (size_t c = 0; c < cells; ++c) {
+            ranges[c * 2] = B.cell_start[c];
+            ranges[c * 2 + 1] = B.cell_start[c + 1];
+        }
+    if (items) std::memcpy(items, B.items.data(), B.refs * sizeof(unsigned));
+    if (big && !B.big.empty()) std::memcpy(big, B.big.data(), B.big.size() * sizeof(int));
+    return RTM_OK;
+}
+
 // Build + upload; a scene that gets no grid keeps sc.grid empty (not an error).  `hg`: the host copy of the geometry rows.
 static int build_scene_grid(rtm_scene& sc, const double* hg, size_t n, int device) {
     GridBuild B;

@@ -221,3 +221,67 @@ def test_edit_epoch_sees_every_write_on_a_scene_object():
     assert tuple(map(id, data.object)) != ids and edit_epoch() == e3  # reordering writes nothing: the ids catch it
     rtm.PlaneObject()
     assert edit_epoch() > e3                                           # construction counts (conservative)
+
+
+def _grid_build(arr, n):
+    info = (C.c_uint64 * 12)()
+    pads = np.zeros(n, dtype=np.float64)
+    rc = _lib.lib().rtm_debug_grid_build(arr, n, info, pads.ctypes.data, None, 0, None, 0, None, 0)
+    if rc != 0:
+        return rc, None
+    cells, recs, nbig = int(info[0]), int(info[1]), int(info[2])
+    ranges = np.zeros(cells * 2, dtype=np.uint32)
+    items = np.zeros(max(recs, 1), dtype=np.uint32)
+    big = np.zeros(max(nbig, 1), dtype=np.int32)
+    _lib.check(_lib.lib().rtm_debug_grid_build(arr, n, info, pads.ctypes.data, ranges.ctypes.data, ranges.size, items.ctypes.data,
+                                               items.size, big.ctypes.data, big.size), "grid build")
+    d = struct.unpack("<6d", bytes(info)[48:96])
+    return 0, dict(cells=cells, recs=recs, dim=[int(info[3 + k]) for k in range(3)], lo=np.array(d[:3]), h=d[3], reach=d[4], t_ok=d[5],
+                   pads=pads, ranges=ranges.reshape(cells, 2), items=items[:recs], big=big[:nbig])
+
+
+def test_grid_builder_lists_cover_every_padded_sphere():
+    """The uniform grid of large scenes (csrc/rtm_kernels.hip: make_grid; the exactness argument is in csrc/rtm_path.h): host logic,
+    no device.  Every point within r + pad of a gridded sphere's centre lies in a cell that lists the sphere — so a hit point,
+    which lies within the pad of the sphere's surface, is always found —, a cell's list ascends (ties go to the lower index by
+    the walk's rule, but the order keeps the lists deterministic), the ranges tile the item array, the spheres that span the
+    scene are in the list every ray tests and nowhere else, and the pads are what the derivation asks for."""
+    rng = np.random.default_rng(12)
+    n = 3000
+    c = rng.uniform(-20, 20, (n, 3))
+    r = rng.uniform(0.05, 1.5, n)
+    c[:4] = [[0, 0, 1e4 + 25], [0, -1e4 - 25, 0], [1e4 + 25, 0, 0], [0, 0, 0]]
+    r[:3] = 1e4
+    r[3] = 0.0
+    arr = (_lib.rtm_sphere * n)()
+    for i in range(n):
+        for k in range(3):
+            arr[i].center[k] = float(c[i, k])
+        arr[i].radius = float(r[i])
+    rc, g = _grid_build(arr, n)
+    assert rc == 0
+    nx, ny, nz = g["dim"]
+    assert g["cells"] == nx * ny * nz and list(g["big"]) == [0, 1, 2]
+    rg = g["ranges"]
+    assert rg[0, 0] == 0 and rg[-1, 1] == g["recs"] and np.array_equal(rg[1:, 0], rg[:-1, 1])  # the ranges tile the items
+    R = np.sqrt((r.astype(np.float32) * r.astype(np.float32)).astype(np.float64))  # the radius the tests use: sqrt(float r*r)
+    # pads: 0.05 h + (sqrt(r^2 + 4e-7 t_ok^2) - r) + 1e-6 t_ok
+    want = 0.05 * g["h"] + (np.sqrt(R * R + 4e-7 * g["t_ok"] ** 2) - R) + 1e-6 * g["t_ok"]
+    assert np.allclose(g["pads"][3:], want[3:], rtol=1e-12, atol=0)
+    lists = [g["items"][a:b] for a, b in rg]
+    for li in lists:
+        assert np.all(np.diff(li.astype(np.int64)) > 0)  # ascending, no duplicates
+    assert not np.isin(g["items"], [0, 1, 2]).any()
+    # coverage: random points within r + pad of the centre (on the inflated surface, and inside) are in a listing cell
+    for i in rng.choice(np.arange(3, n), 400, replace=False):
+        v = rng.normal(size=(40, 3))
+        v /= np.linalg.norm(v, axis=1)[:, None]
+        rad = (R[i] + g["pads"][i]) * np.concatenate([np.full(20, 1.0 - 1e-9), rng.uniform(0, 1, 20)])
+        p = c[i] + v * rad[:, None]
+        cell = np.floor((p - g["lo"]) / g["h"]).astype(int)
+        assert (cell >= 0).all() and (cell < [nx, ny, nz]).all()  # the box holds every padded sphere
+        for cx, cy, cz in cell:
+            assert i in lists[(cz * ny + cy) * nx + cx], (i, cx, cy, cz)
+    # too few gridded spheres: no grid
+    few = (_lib.rtm_sphere * 40)(*arr[4:44])
+    assert _grid_build(few, 40)[0] == _lib.lib().rtm_debug_grid_build(few, 40, (C.c_uint64 * 12)(), None, None, 0, None, 0, None, 0) != 0
