@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     double* trig = cam + 10;                           // 16 sincos constants
     RecT* rec = reinterpret_cast<RecT*>(trig + kTrigConstCount);
     unsigned* next_unit = reinterpret_cast<unsigned*>(rec + LDS_D * 64);
+    unsigned char* queue = reinterpret_cast<unsigned char*>(next_unit + 4);  // the walks' candidate queue (16-byte aligned)
     if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     };
     bool busy = take_unit();
     GridWalk<MathFast, SceneGlobal> walk;
+    walk.attach_queue(queue, 64, lane);
     bool walking = false;
     while (__builtin_amdgcn_ballot_w64(busy) != 0) {  // wave-uniform
         if (busy && !walking) walking = walk.begin(sc, org, dir);

@@ -1603,7 +1603,8 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx) {
     }
     P.contrib = static_cast<unsigned char*>(ws);
     const bool deep = needs_pool(P);
-    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 + debug_lds_pad();
+    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
+                       GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
     for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
         const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);
         P.xcd_on = xcd_off ? 0u : 1u;

@@ -903,6 +903,22 @@ struct GridWalk {
     unsigned j, jend, nj, nje;  // records left in the current cell; the next cell's list
     bool next_ok;               // the next cell is inside the grid
     unsigned tests, steps;      // (COUNT: the probe's diagnostics, rtm_debug_grid_nearest)
+    // Candidates — records whose discriminant came out >= 0 — wait in LDS for their square root: one lane in seven per
+    // test, so the root taken on the spot was paid by the whole wave in 73 % of the test slots for 5 lanes
+    // (profiles/r3/grid_occupancy.txt); queued, every trip takes ONE root for all lanes that have a candidate.
+    // kGridBatch entries per lane, [entry][lane]: b, D4 (doubles) and the sphere's index.
+    unsigned pending;  // this lane's queued candidates
+    double* q_b;       // wave-uniform LDS pointers, already offset by the lane; entries `q_stride` elements apart
+    double* q_d;
+    unsigned* q_i;
+    int q_stride;
+    static constexpr size_t queue_bytes(int lanes) { return (size_t)kGridBatch * lanes * (2 * sizeof(double) + sizeof(unsigned)); }
+    __device__ __forceinline__ void attach_queue(unsigned char* lds, int lanes, int lane) {
+        q_b = reinterpret_cast<double*>(lds) + lane;
+        q_d = q_b + (size_t)kGridBatch * lanes;
+        q_i = reinterpret_cast<unsigned*>(reinterpret_cast<double*>(lds) + (size_t)2 * kGridBatch * lanes) + lane;
+        q_stride = lanes;
+    }
 
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(4))) GridHeader* HdrPtr;
@@ -952,6 +968,7 @@ struct GridWalk {
         RTM_GRID_OCC(0);
         best = -1;
         dis = DBL_MAX;
+        pending = 0u;
         if constexpr (COUNT) tests = steps = 0;
         const int n_big = G->n_big;
         const int* big = G->big;
@@ -1038,45 +1055,71 @@ struct GridWalk {
     __device__ __forceinline__ bool advance(const Scene& sc, const D3 org, const D3 dir) {
         HdrPtr G = header(sc);
         RTM_GRID_OCC(1);
-        if (j >= jend) {
-            RTM_GRID_OCC(2);
-            // this cell is done: every sphere that can be hit before its exit has been tested (see above)
-            if (dis <= t_exit || !next_ok) return false;
-            if constexpr (COUNT) ++steps;
-            j = nj;
-            jend = nje;
-            plan_next(G);
-        }
-        // Up to kGridBatch of the cell's records, all loads first.  The loads and tests are per lane (a lane with two
-        // records left issues two loads): the walk is bound by the vector memory pipeline, which pays per lane and
-        // distinct line (profiles/r3/grid_variants.txt: the same loads issued twice cost +31 %, the tests' arithmetic
-        // twice +8 %), so nothing is fetched that is not needed.
-        const double4* recs = G->recs + j;
-        const unsigned left = jend - j;
-        double4 r[kGridBatch];
-#pragma unroll
-        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k)
-            if (left > k) r[k] = recs[k];
-#pragma unroll
-        for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
-            if (left > k) {
-                RTM_GRID_OCC(3 + k);
-                // the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
-                const unsigned long long w = (unsigned long long)__double_as_longlong(r[k].w);
-                double4 g = r[k];
-                g.w = __longlong_as_double((long long)(w & ~0x1FFFFFFFull));
-                consider((int)((unsigned)w & 0x1FFFFFFFu), g, org, dir);
+        if (pending == 0u) {
+            if (j >= jend) {
+                RTM_GRID_OCC(2);
+                // this cell is done and its candidates are settled: every sphere that can be hit before its exit has been
+                // tested (see above)
+                if (dis <= t_exit || !next_ok) return false;
+                if constexpr (COUNT) ++steps;
+                j = nj;
+                jend = nje;
+                plan_next(G);
             }
+            // Up to kGridBatch of the cell's records, all loads first.  The loads and tests are per lane (a lane with two
+            // records left issues two loads): the walk is bound by the vector memory pipeline, which pays per lane and
+            // distinct line (profiles/r3/grid_perturbation.txt: the same loads issued twice cost +31 %, the tests'
+            // arithmetic twice +8 %), so nothing is fetched that is not needed.
+            const double4* recs = G->recs + j;
+            const unsigned left = jend - j;
+            double4 r[kGridBatch];
+#pragma unroll
+            for (unsigned k = 0; k < (unsigned)kGridBatch; ++k)
+                if (left > k) r[k] = recs[k];
+#pragma unroll
+            for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
+                if (left > k) {
+                    RTM_GRID_OCC(3 + k);
+                    if constexpr (COUNT) ++tests;
+                    // src/SettingData.cpp:198-200; the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
+                    const unsigned long long w = (unsigned long long)__double_as_longlong(r[k].w);
+                    const D3 p_o = d3(r[k].x - org.x, r[k].y - org.y, r[k].z - org.z);
+                    const double b = dot(p_o, dir);
+                    const double D4 = b * b - dot(p_o, p_o) + __longlong_as_double((long long)(w & ~0x1FFFFFFFull));
+                    if (D4 >= 0.0) {  // :202 (a NaN D4 would end in a NaN t: never accepted)
+                        const unsigned at = pending * (unsigned)q_stride;
+                        q_b[at] = b;
+                        q_d[at] = D4;
+                        q_i[at] = (unsigned)w & 0x1FFFFFFFu;
+                        ++pending;
+                    }
+                }
+            }
+            j = left > (unsigned)kGridBatch ? j + (unsigned)kGridBatch : jend;
         }
-        j = left > (unsigned)kGridBatch ? j + (unsigned)kGridBatch : jend;
+        if (pending != 0u) {  // one candidate per lane and trip: :205-223 and the caller's acceptance (src/Renderer.cpp:67)
+            RTM_GRID_OCC(7);
+            --pending;
+            const unsigned at = pending * (unsigned)q_stride;
+            const double b = q_b[at], D4 = q_d[at];
+            const int i = (int)q_i[at];
+            const double sq = M::sqrt64(D4);
+            const double t1 = b - sq, t2 = b + sq;
+            const double t = (t1 > 0.001) ? t1 : t2;  // accepted as in sphere_update, ties to the lower index
+            const bool accept = !(t < (double)1e-5f) && (t < dis || (t == dis && i < best));
+            dis = accept ? t : dis;
+            best = accept ? i : best;
+        }
         return true;
     }
 };
 
 template <class M, class Scene, bool COUNT = false>
 __device__ __forceinline__ int nearest_hit_grid(const Scene& sc, const D3 org, const D3 dir, double& dis,
+                                                unsigned char* queue_lds, int queue_lanes, int queue_lane,
                                                 unsigned* n_tests = nullptr, unsigned* n_steps = nullptr) {
     GridWalk<M, Scene, COUNT> W;
+    W.attach_queue(queue_lds, queue_lanes, queue_lane);
     bool walking = W.begin(sc, org, dir);
     while (walking) walking = W.advance(sc, org, dir);
     if constexpr (COUNT) {

@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256) void grid_probe_kernel(SceneView scene, const 
     sc.v = scene;
     double dis;
     unsigned tests, steps;
+    __shared__ __attribute__((aligned(16))) unsigned char queue[GridWalk<MathFast, SceneGlobal, true>::queue_bytes(256)];
     const int id = nearest_hit_grid<MathFast, SceneGlobal, true>(sc, d3(org[r], org[n_rays + r], org[2 * (size_t)n_rays + r]),
                                                                  d3(dir[r], dir[n_rays + r], dir[2 * (size_t)n_rays + r]), dis,
-                                                                 &tests, &steps);
+                                                                 queue, 256, (int)threadIdx.x, &tests, &steps);
     if (i < n_rays) {
         out_id[i] = id;
         out_t[i] = dis;
