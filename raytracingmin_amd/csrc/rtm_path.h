@@ -841,8 +841,6 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
     }
 }
 
-// src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
-// UNROLL == 1: the literal loop.  UNROLL > 1: batches of UNROLL spheres (sphere_batch).
 // ------------------------------------------------------------------------------------------------
 // The nearest-hit loop of src/Renderer.cpp:58-73 for LARGE scenes, through a uniform grid: the same (hit object, dis)
 // as the loop over all objects, from a fraction of its Intersect calls.
@@ -853,7 +851,7 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 // t^2 - 2bt + (|c - o|^2 - r^2), so the point o + t d lies at distance sqrt(r^2 + t^2 (d.d - 1)) of the centre:
 // on the sphere but for the direction's float-normalised length (|d.d - 1| <= 1.8e-7, src/Ray.h:67-72) and rounding.
 // (The reference's loop in effect sees every sphere inflated to that radius: a far, tiny sphere is "hit" by rays that
-// pass it at up to sqrt(|d.d - 1|) t.)  Each sphere is listed in every cell within pad_i of its box,
+// pass it at up to sqrt(|d.d - 1|) t.)  Each sphere is listed in every cell that lies within r_i + pad_i of its centre,
 // pad_i = 0.05 h + (sqrt(r_i^2 + dd_tol t_ok^2) - r_i) + 1e-6 t_ok, which covers that excess for every t <= t_ok and
 // |d.d - 1| <= dd_tol = 4e-7, the rounding of t itself (<= 1e-7 t for a grazing hit), the DDA's own rounding (1e-12)
 // by ten orders of magnitude, and a sphere hit in a cell the DDA cuts at a corner (it is listed in the neighbours too).
@@ -868,7 +866,7 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 #ifndef RTM_GRID_K
 #define RTM_GRID_K 4
 #endif
-constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_tune.txt)
+constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_crossover.txt)
 #ifndef RTM_GRID_SHADE_AT
 #define RTM_GRID_SHADE_AT 4
 #endif
@@ -891,7 +889,7 @@ __device__ unsigned long long g_grid_occ[32];
 #endif
 
 // One ray's walk through the grid, as per-lane state that can be advanced a trip at a time: the render kernel's lanes
-// walk independently and are shaded in groups (rtm_render_kernel.h), the probe and the plain nearest_hit run it to the end.
+// walk independently and are shaded in groups (rtm_grid_kernel.h), the probe runs it to the end.
 template <class M, class Scene, bool COUNT = false>
 struct GridWalk {
     double dis;  // the nearest accepted hit so far (DBL_MAX: none) and its object
@@ -1130,8 +1128,10 @@ __device__ __forceinline__ int nearest_hit_grid(const Scene& sc, const D3 org, c
     return W.best;
 }
 
+// src/Renderer.cpp:58-73: brute-force nearest hit; strict < keeps the lowest index on ties.
+// UNROLL == 1: the literal loop.  UNROLL > 1: batches of UNROLL spheres (sphere_batch).
 template <class M, int UNROLL, class Scene>
-__device__ __forceinline__ int nearest_hit_loop(const Scene& sc, const D3 org, const D3 dir, double& dis) {
+__device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
     int hit_object = -1;
     dis = DBL_MAX;
     const int n = sc.n();
@@ -1187,11 +1187,6 @@ __device__ __forceinline__ int nearest_hit_loop(const Scene& sc, const D3 org, c
         }
     }
     return hit_object;
-}
-
-template <class M, int UNROLL, class Scene>
-__device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const D3 dir, double& dis) {
-    return nearest_hit_loop<M, UNROLL>(sc, org, dir, dis);
 }
 
 struct PathCounters {
