@@ -293,9 +293,9 @@ static SceneView scene_view(const double* geom, const double* mat, const double*
     return v;
 }
 
-// ---- uniform grid of a large scene (rtm_path.h: GridHeader, nearest_hit_grid — where the pads are derived) ----------
-// Built on the host from the flattened geometry rows (cx, cy, cz, float r*r) when a scene OBJECT is created: a few
-// milliseconds for 100 000 spheres, once per scene.  ~kGridCellsPerSphere cells per sphere; a sphere whose padded box
+// ---- uniform grid of a large scene (rtm_path.h: GridHeader, GridWalk — where the pads are derived) ------------------
+// Built on the host from the flattened geometry rows (cx, cy, cz, float r*r) when a scene OBJECT is created: 25 ms for
+// 100 000 spheres on one core, once per scene.  ~2 cells per sphere (RTM_DEBUG_GRID_CELLS); a sphere whose padded box
 // covers more than kGridBigCells cells goes to the list every ray tests.  No grid (the other kernels serve the scene)
 // for fewer than kGridMinSpheres gridded spheres (below that the packed-record kernels are as fast or faster:
 // profiles/r3/grid_crossover.txt), non-finite geometry, more than kGridMaxBig big spheres or planes.
