@@ -176,7 +176,7 @@ int rtm_stream_release(int device, void* stream);
  * spheres_on_device != 0) and uploads the tables; it returns when they are resident, so the caller's
  * array may be freed at once.  A scene belongs to one device.
  * For an all-sphere scene of 64 spheres or more (not counting those that span the scene, like the Cornell walls) the
- * call also builds, on the host (~40 ms per 100 000 spheres), a uniform grid over the spheres (~32 B x 6 per sphere +
+ * call also builds, on the host (~25 ms per 100 000 spheres plus the upload), a uniform grid over the spheres (~32 B x 6 per sphere +
  * 8 B per cell, ~2 cells per sphere): renders then find the reference loop's nearest hit (src/Renderer.cpp:58-73:
  * same object, same distance, same image) through the grid instead of testing every sphere for every cast
  * (rtm_options.variant 17; variant 0 picks it when the camera is within about two scene diagonals of the scene;
