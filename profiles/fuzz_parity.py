@@ -76,6 +76,24 @@ for case in range(cases):
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED
     if data.has_planes():
         variant = int(rng.choice([0, 0, 1, 2, 9]))
+    only = os.environ.get("FUZZ_ONLY")  # replay ONE case (the random stream is consumed as in the full run) ...
+    if only is not None and case != int(only):
+        continue
+    if only is not None and not data.has_planes():
+        # ... through several kernels, against each other and the oracle: is a mismatch one kernel's, or everybody's?
+        st, arr, cnt_n = data.to_c()
+        ost = oracle.Settings.from_buffer_copy(bytes(st))
+        oarr = (oracle.Sphere * max(cnt_n, 1)).from_buffer_copy(bytes(arr))
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
+        print("case", case, dict(n=n, w=data.width, h=data.height, S=data.samples, SS=data.superSamples, max_bounces=mb, mode=mode),
+              "oracle casts", cnt["casts"], "draws", cnt["draws"])
+        for v in [int(x) for x in os.environ.get("FUZZ_VARIANTS", "1,3,17").split(",")]:
+            out, stats = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=v, host_trig=host_trig).render_rows(
+                0, data.height, want=("f64",))
+            print("  variant", v, "image == oracle:", bool(np.array_equal(out["f64"], ref, equal_nan=True)), "casts", stats["casts"],
+                  "draws", stats["draws"], "max delta", float(np.nanmax(np.abs(out["f64"] - ref))))
+        continue
+    if data.has_planes():
         oarr_c, cnt_n = data.objects_c()
         oobj = (oracle.Object * max(cnt_n, 1)).from_buffer_copy(bytes(oarr_c))
         ost = oracle.Settings.from_buffer_copy(bytes(data.settings_c()))

@@ -321,3 +321,42 @@ print(st["casts"])
         casts.append(int(r.stdout.strip().splitlines()[-1]))
         os.remove(path)
     assert np.array_equal(frames[0].view(np.uint64), frames[1].view(np.uint64)) and casts[0] == casts[1]
+
+
+def test_grid_through_every_entry_point(rtm, oracle):
+    """A 2 000-sphere scene through the C ABI's entry points: a scene object made from a HOST array and one made from a
+    DEVICE array (its geometry rows come back once for the host-side grid build) both render through the grid
+    (rtm_stats.variant 17); the array entry points use the scene cache for a host array (grid) and per-call tables for a
+    device array (no scene object: the exhaustive pipeline) — one frame, bit for bit, from all of them."""
+    import ctypes as C
+    import torch
+    L = rtm.lib()
+    data = rtm.make_stress_scene(n=2000, seed=21)
+    data.width, data.height, data.samples, data.superSamples = 72, 40, 4, 1
+    st = data.settings_c()
+    arr, n = data.spheres_c()
+    ost, oarr, _ = _oracle_view(oracle, data)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=3, height=40))
+    opt = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3)._options(0, 40)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_arr = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+
+    def frame(call):
+        out = torch.empty((40, 72, 3), dtype=torch.float64, device="cuda")
+        stats = rtm._lib.rtm_stats()
+        rtm._lib.check(call(C.c_void_p(out.data_ptr()), C.byref(stats)), "render")
+        return out.cpu().numpy(), stats.variant, stats.casts
+
+    h_host, h_dev = C.c_void_p(), C.c_void_p()
+    rtm._lib.check(L.rtm_scene_create(arr, n, 0, 0, C.byref(h_host)), "rtm_scene_create")
+    rtm._lib.check(L.rtm_scene_create(C.c_void_p(d_arr.data_ptr()), n, 1, 0, C.byref(h_dev)), "rtm_scene_create(device)")
+    results = [
+        frame(lambda o, s: L.rtm_render_scene(C.byref(st), h_host, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_scene(C.byref(st), h_dev, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), o, None, None, stream, s)),
+        frame(lambda o, s: L.rtm_render_device(C.byref(st), C.c_void_p(d_arr.data_ptr()), n, 1, C.byref(opt), o, None, None, stream, s)),
+    ]
+    assert [v for _, v, _ in results] == [17, 17, 17, 12]
+    for f, _, casts in results:
+        assert np.array_equal(f.view(np.uint64), ref.view(np.uint64)) and casts == cnt["casts"]
+    assert L.rtm_scene_destroy(h_host) == 0 and L.rtm_scene_destroy(h_dev) == 0
