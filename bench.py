@@ -146,7 +146,7 @@ def valu_issue_view(pmc, source):
             "measured_in_run": False, "source": source}
 
 
-def other_configs(rtm, cfg, device, host_trig, full_c5=False):
+def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
     """BASELINE configs[1], configs[4] (the full frame through the grid kernel, a strip — the full frame with
     --full-c5-exhaustive — through the exhaustive pipeline), the plane scene and the two labelled rows, measured in this run, outside the timed region.  Every group of rows stands alone: a failure is
     recorded under its name and the others are still measured."""
@@ -253,6 +253,26 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False):
                                                  "(rocprofv3 --pmc, separate passes; profiles/prof_c5_grid.sh): the per-sample "
                                                  "terms written once and read once (2 x 17 GB) and the L2 misses of the 22 MB "
                                                  "of cell lists, served mostly by the Infinity Cache"}
+        if cpu_rows > 0:
+            # the CPU port beside it (timed on a crop and scaled — the reference's loop makes 100 000
+            # Intersect calls per cast): a 96x96 block of pixels in the middle of the frame at 4 spp, every host core
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle
+            import numpy as np
+            crop = rtm.make_stress_scene(n=100_000, seed=12345)
+            crop.width, crop.height, crop.samples, crop.superSamples = 1920, 1080, 4, 1
+            cst, carr, cn = crop.to_c()
+            ost = _oracle.Settings.from_buffer_copy(bytes(cst))
+            oarr = (_oracle.Sphere * cn).from_buffer_copy(bytes(carr))
+            xy = np.stack(np.meshgrid(np.arange(912, 1008), np.arange(492, 588)), axis=-1).reshape(-1, 2).astype(np.int32)
+            threads = _oracle.lib().rtmo_max_threads()
+            t0 = time.perf_counter()
+            _oracle.render_pixels(ost, oarr, cn, _oracle.make_options(mode=1, max_bounces=8, seed=cfg["seed"], height=1080), xy,
+                                  threads=threads)
+            cdt = time.perf_counter() - t0
+            row["cpu_baseline"] = {"value": len(xy) * 4 / cdt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                                   "sample": f"a 96x96 block of the frame's pixels at 4 spp ({len(xy) * 4} samples, {cdt:.2f} s wall, "
+                                             "OpenMP per-pixel parallel, the reference's loop over all 100 000 spheres)"}
         out["c5_stress_100k_full_1080p_256spp"] = row
 
         # the exhaustive large-scene pipeline (variant 12: every cast tests all 100 000 spheres, packed-fp32 rejection
@@ -622,7 +642,7 @@ def main():
                                         "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
         if world == 1 and not args.no_extras and headline:
             try:
-                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=args.full_c5_exhaustive)
+                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=args.full_c5_exhaustive, cpu_rows=args.cpu_rows)
             except Exception as exc:
                 extras_failed["other_configs"] = repr(exc)
         if extras_failed:
