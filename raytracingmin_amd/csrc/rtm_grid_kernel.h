@@ -11,7 +11,7 @@
 //     (seed, global pixel, sample, draw), so any lane can trace any unit; all 64 lanes finish within one unit of each
 //     other whatever the pixels cost.
 //   * lanes walk independently and are shaded in groups: each trip of the loop advances the walks until at least
-//     kGridShadeAt8 / 8 of the busy lanes have finished theirs, shades those (they start their next ray, or fold their
+//     kGridShadeAt8 / 8 (five eighths) of the busy lanes have finished theirs, shades those (they start their next ray, or fold their
 //     path and take the next unit) and leaves the others walking.
 //   * the sum over a pixel's samples must be added in sample order (src/Renderer.cpp:241-242; fp64 addition does not
 //     commute bitwise), and the samples of a pixel now finish on different lanes in any order: every sample's term

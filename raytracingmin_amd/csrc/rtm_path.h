@@ -868,7 +868,7 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 #endif
 constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_crossover.txt)
 #ifndef RTM_GRID_SHADE_AT
-#define RTM_GRID_SHADE_AT 4
+#define RTM_GRID_SHADE_AT 5
 #endif
 constexpr int kGridShadeAt8 = RTM_GRID_SHADE_AT;  // the render loop shades when this many eighths of a wave's lanes have finished their walks
 
