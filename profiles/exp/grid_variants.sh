@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r3
 out=gpurun_out/r3/grid_variants.txt
 : > $out
-echo "default (K=4, 4 waves/SIMD, shade at 4/8):" >> $out
+echo "default (K=4, 4 waves/SIMD, shade at 5/8):" >> $out
 timeout -k 10 300 python profiles/exp/grid_tune.py 0 1080 >> $out 2>&1
 for v in "$@"; do
   echo "$v:" >> $out
