@@ -1379,6 +1379,9 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
     // the last 3/8 of a round of tiles (1 536 on this chip; profiles/r2/tail_split.txt).  1 024 would keep the launch's term
     // traffic under 2 GB (profiles/r3/term_store_modes.txt) but costs the headline frame 0.5 % and a one-round launch like
     // 512 x 512 x 256 spp 17 % (8.0 against 6.9 ms: there the slowest WHOLE tile sets the time; profiles/r3/ab_r2_vs_r3.txt)
+    // (Re-checked with in-wave sample stealing in place, profiles/r3/tail_after_steal.txt: still the best single value — a
+    // longer tail helps some contiguous strips, the frame's top rows by 12 %, and costs the interleaved-band parts of a
+    // multi-GPU frame 4 %.)
     unsigned tail = forced ? n_tiles : env_tail >= 0 ? (unsigned)env_tail : 3u * slots / 8u;
     if (tail > n_tiles) tail = n_tiles;
     while (tail > 64u && !forced && !fits(g, tail)) tail /= 2u;  // very many samples per pixel: a shorter tail whose terms fit
