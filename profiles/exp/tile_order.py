@@ -1,6 +1,7 @@
 """EXPERIMENT: what a cost-aware tile order would buy.  Per-tile cost = the oracle's casts for the tile's pixels at `spp_est` samples
 (CPU, this container or the GPU box); order = whole tiles in descending cost, then the `tail` MOST expensive tiles, which the sample
-split cuts (they come last in the launch's logical order).  Writes a u32 file for RTM_DEBUG_TILE_ORDER_FILE.
+split cuts (they come last in the launch's logical order).  Writes a u32 file for RTM_DEBUG_TILE_ORDER_FILE — a knob of a library built with
+profiles/r3/tile_order_experiment.patch applied (git apply; the product does not read it).  Result: profiles/r3/tail_after_steal.txt.
     python profiles/exp/tile_order.py <width> <height> <row_begin> <row_end> <bands N> <band index> <tail> <out file> [mode]
 mode: "expensive-split" (default) or "cheap-split" (descending cost throughout: the cheapest tiles are the split ones)"""
 import os

@@ -1,4 +1,5 @@
-# EXPERIMENT: kernel ms with a cost-aware tile order (files made by profiles/exp/tile_order.py into ab_libs/orders/) against the plain order
+# EXPERIMENT: kernel ms with a cost-aware tile order (files made by profiles/exp/tile_order.py into ab_libs/orders/) against the plain order.
+# Needs a library built with profiles/r3/tile_order_experiment.patch applied (the product does not read RTM_DEBUG_TILE_ORDER_FILE).
 cd $GRAFT_REPO_ROOT
 one() { python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$1', round(j['ms_per_step'],3))"; }
 for o in none c2_exp c2_cheap; do
