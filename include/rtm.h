@@ -179,7 +179,8 @@ int rtm_stream_release(int device, void* stream);
  * call also builds, on the host (~25 ms per 100 000 spheres plus the upload), a uniform grid over the spheres (~32 B x 6 per sphere +
  * 8 B per cell, ~2 cells per sphere): renders then find the reference loop's nearest hit (src/Renderer.cpp:58-73:
  * same object, same distance, same image) through the grid instead of testing every sphere for every cast
- * (rtm_options.variant 17; variant 0 picks it when the camera is within about two scene diagonals of the scene;
+ * (rtm_options.variant 17; variant 0 picks it when the camera is within about two scene diagonals of the scene and no
+ * diffuse sphere encloses the scene from farther away than that — its bounces would start where the grid cannot serve them;
  * variants 3 / 14 and, from 512 spheres, 12 are the exhaustive kernels). */
 int rtm_scene_create(const rtm_sphere* spheres, size_t n_spheres, int spheres_on_device, int device,
                      rtm_scene** out_scene);

@@ -245,6 +245,7 @@ struct rtm_scene {
     rtm::DevMem grid;                   // large all-sphere scenes: GridHeader + cell offsets + cell lists + big list
     size_t grid_cells = 0, grid_refs = 0, grid_big = 0;
     rtm::GridHeader grid_hdr;           // host copy (grid_for: is the camera within the pads' reach?)
+    bool grid_far_bounces = false;      // a diffuse sphere encloses the gridded ones from beyond the pads' reach (build_scene_grid)
     bool has_planes = false;
     uint64_t content_hash = 0;            // cache entries only ...
     std::vector<unsigned char> content;   // ... and the bytes the hash was taken of (compared on a hash hit)
@@ -496,9 +497,21 @@ int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads
 }
 
 // Build + upload; a scene that gets no grid keeps sc.grid empty (not an error).  `hg`: the host copy of the geometry rows.
-static int build_scene_grid(rtm_scene& sc, const double* hg, size_t n, int device) {
+// `hm`: the material rows (kd in column 6), or null.
+static int build_scene_grid(rtm_scene& sc, const double* hg, const double* hm, size_t n, int device) {
     GridBuild B;
     if (sc.has_planes || !make_grid(hg, n, B)) return RTM_OK;
+    // A diffuse sphere that ENCLOSES the gridded ones from farther away than the pads reach (an environment sphere) sends
+    // its bounces back from origins the walk cannot serve: each of them would take the exhaustive loop inside the grid
+    // kernel, one lane at a time.  Such a scene keeps its grid for variant 17 by name; variant 0 leaves it alone (grid_for).
+    sc.grid_far_bounces = false;
+    const double reach = std::sqrt(B.hdr.reach2);
+    for (int i : B.big) {
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) d2 += (hg[(size_t)i * 4 + k] - B.hdr.cb[k]) * (hg[(size_t)i * 4 + k] - B.hdr.cb[k]);
+        const bool diffuse = !hm || hm[(size_t)i * 8 + 6] > 0.0;
+        if (diffuse && std::sqrt(hg[(size_t)i * 4 + 3]) - std::sqrt(d2) > reach) sc.grid_far_bounces = true;
+    }
     const size_t off_cs = (sizeof(GridHeader) + 255) & ~(size_t)255;
     const size_t n_cells = B.cell_start.size() - 1;
     std::vector<unsigned> ranges(n_cells * 2);  // (first, one past last) per cell: one 8-byte load per cell step
@@ -555,7 +568,7 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
-    return want_grid ? build_scene_grid(sc, hg.data(), n, device) : RTM_OK;
+    return want_grid ? build_scene_grid(sc, hg.data(), hm.data(), n, device) : RTM_OK;
 }
 // The same from a DEVICE sphere array.
 static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n, int device) {
@@ -574,7 +587,9 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
     if (n < kGridMinSpheres) return RTM_OK;
     std::vector<double> hg(n * 4);  // the grid is built on the host: the geometry rows come back once
     RTM_HIP_CHECK(hipMemcpy(hg.data(), sc.geom.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost));
-    return build_scene_grid(sc, hg.data(), n, device);
+    std::vector<double> hm((n + 1) * 8);
+    RTM_HIP_CHECK(hipMemcpy(hm.data(), sc.mat.p, hm.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return build_scene_grid(sc, hg.data(), hm.data(), n, device);
 }
 
 int scene_create(const rtm_sphere* sp, size_t n, int on_device, int device, rtm_scene** out) {
@@ -1839,6 +1854,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
 static const void* grid_for(const rtm_scene* sc, const rtm_settings* st, const rtm_options* opt) {
     if (!sc->grid.p) return nullptr;
     if (opt->variant == kVariantGrid) return sc->grid.p;
+    if (sc->grid_far_bounces) return nullptr;
     double d2 = 0.0;
     for (int k = 0; k < 3; ++k) d2 += (st->camera.origin[k] - sc->grid_hdr.cb[k]) * (st->camera.origin[k] - sc->grid_hdr.cb[k]);
     return (d2 <= sc->grid_hdr.reach2) ? sc->grid.p : nullptr;  // (NaN: no)

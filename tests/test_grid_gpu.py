@@ -360,3 +360,21 @@ def test_grid_through_every_entry_point(rtm, oracle):
     for f, _, casts in results:
         assert np.array_equal(f.view(np.uint64), ref.view(np.uint64)) and casts == cnt["casts"]
     assert L.rtm_scene_destroy(h_host) == 0 and L.rtm_scene_destroy(h_dev) == 0
+
+
+def test_environment_sphere_keeps_variant_0_off_the_grid(rtm, oracle):
+    """A diffuse sphere that encloses the gridded spheres from beyond the pads' reach (an environment sphere) sends its
+    bounces back from origins the walk cannot serve (csrc/rtm_kernels.hip: build_scene_grid): variant 0 leaves such a
+    scene to the exhaustive kernels; variant 17 by name sends those rays through its exhaustive loop — the oracle's frame
+    either way.  A black emissive environment sphere never bounces (kd = 0): variant 0 keeps the grid."""
+    for colour, expect_grid in (((0.6, 0.6, 0.7), False), ((0.0, 0.0, 0.0), True)):
+        data = rtm.make_stress_scene(n=2000, seed=17)
+        data.object.append(rtm.SphereObject(rtm.vec3(0, 0, 0), 3000.0, rtm.Material(rtm.vec3(*colour), rtm.vec3(0.8, 0.8, 0.8))))
+        data.width, data.height, data.samples, data.superSamples = 24, 16, 2, 1
+        ost, oarr, n = _oracle_view(oracle, data)
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=8, seed=13, height=16))
+        auto, st0 = _image(rtm, data, "repaired", 8, 13, 0)
+        named, st17 = _image(rtm, data, "repaired", 8, 13, 17)
+        assert (st0["variant"] == 17) == expect_grid and st17["variant"] == 17
+        assert np.array_equal(auto["f64"].view(np.uint64), ref.view(np.uint64)) and st0["casts"] == cnt["casts"]
+        assert np.array_equal(named["f64"].view(np.uint64), ref.view(np.uint64)) and st17["casts"] == cnt["casts"]
