@@ -106,6 +106,82 @@ def measured_fp64_peak(rtm):
                    "price list of the same method: profiles/r3/fp64_peak.txt)"}
 
 
+KERNEL_OF_VARIANT = {1: "render_tiles_kernel (per-object loop, compiler math)", 2: "render_tiles_kernel", 3: "render_tiles_kernel",
+                     7: "render_tiles_kernel (stamped)", 9: "render_tiles_kernel", 12: "wf_nearest_f32_kernel + wf_shade_kernel",
+                     14: "render_tiles_kernel", 15: "render_tiles_kernel (primary-hit reuse)", 16: "render_fp32_kernel",
+                     17: "render_grid_kernel + grid_finalize_kernel", 18: "rtm_tol::render_tiles_kernel (+ prim_mask_kernel)"}
+
+
+def roofline_of(st, kernel_ms, n_objects, width, d4_fraction=None, peak_measured=None, replay=None):
+    """The roofline object of ONE measured row, from the library's own account of what ran (rtm_stats.variant) — never from
+    the scene's size.  st: the stats of an instrumented step of the row; kernel_ms: its render kernels' time.
+      exhaustive fp64 kernels (1, 2, 3, 9, 14, 15, 18)  the reference's flops per sample against the fp64
+                                                        vector peak;
+      12, the exhaustive large-scene pipeline           16 flops (8 packed-fp32 FMAs) per (ray, sphere) pair against the
+                                                        packed-fp32 peak;
+      16, the labelled fp32 row                         the reference's flops against the fp32 peak;
+      17, the uniform grid                              NO flop roofline: the kernel returns the reference loop's answer
+                                                        from a different algorithm, so pricing it at the reference's 17 N
+                                                        flops per cast would report work it does not do.  It gets the
+                                                        HBM view the contract defines (algorithmic bytes / time), its
+                                                        measured sphere tests per cast, the factor by which that undercuts
+                                                        the reference's loop, and (replayed from the committed profile)
+                                                        VALU busy x active lanes and the counter traffic.
+    frac is never above 1."""
+    variant = st["variant"]
+    samples, casts, bounces = st["samples"], st["casts"], st["bounces"]
+    cps, bps = casts / samples, bounces / samples
+    t = kernel_ms * 1e-3
+    out = {"kernel": KERNEL_OF_VARIANT.get(variant, f"variant {variant}"), "kernel_ms": kernel_ms, "variant": variant,
+           "casts_per_sample": cps, "bounces_per_sample": bps, "measured_in_run": True}
+    alg_bytes = st["pixels"] * 12 + n_objects * 96 if st.get("pixels") else None
+    if variant == 17:
+        grid_bytes = (replay or {}).get("grid_bytes")
+        ab = (alg_bytes or 0) + (grid_bytes or 0)
+        ach = ab / t / 1e9
+        out.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": min(1.0, ach / PEAK_HBM_GBS),
+                    "algorithmic_bytes_per_launch": ab,
+                    "traffic": (replay or {}).get("traffic"), "traffic_source": (replay or {}).get("traffic_source"),
+                    "flop_roofline": None,
+                    "reference_object_tests_per_cast": n_objects,
+                    "reference_flops_per_cast": 17.0 * n_objects + 18.0,
+                    "note": "the nearest hit of the reference's loop over all objects (src/Renderer.cpp:58-73) through a uniform "
+                            "grid: same hit object, distance and image from a fraction of the Intersect calls — a different "
+                            "algorithm for the same answer, so there is no flop roofline on the reference's work model (priced at "
+                            "17 N flops per cast the row would read thousands of TFLOP/s).  Bound by per-lane gathers and lane "
+                            "divergence, not by HBM: the HBM view is the contract's, reported, and tiny."})
+        if st.get("object_tests"):
+            tpc = st["object_tests"] / casts
+            out.update({"object_tests_per_cast": tpc, "object_tests_source": "rtm_stats.object_tests of a counting render of the same "
+                        "frame in this run (RTM_MODE_COUNT_TESTS)", "undercuts_reference_tests_by": n_objects / tpc,
+                        "object_tests_per_s": st["object_tests"] / t})
+        if replay and replay.get("valu_issue"):
+            out["valu_issue"] = replay["valu_issue"]
+        return out
+    if variant == 12:
+        tests_per_s = casts * n_objects / t
+        ach = tests_per_s * 16.0 / 1e12
+        out.update({"bound": "valu-fp32", "achieved": ach, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                    "frac": min(1.0, ach / PEAK_FP32_VECTOR_TFLOPS), "object_tests_per_s": tests_per_s,
+                    "traffic": (replay or {}).get("traffic"), "traffic_source": (replay or {}).get("traffic_source"),
+                    "note": "brute force over every sphere; a pair whose discriminant is provably negative is rejected by 8 "
+                            "packed-fp32 FMAs (16 flops, counted here), the rest get the reference's fp64 arithmetic"})
+        return out
+    d4 = 0.0 if d4_fraction is None else d4_fraction
+    f_sample = algorithmic_flops_per_sample(n_objects, cps, bps, d4)
+    ach = f_sample * samples / t / 1e12
+    peak = PEAK_FP32_VECTOR_TFLOPS if variant == 16 else PEAK_FP64_VECTOR_TFLOPS
+    out.update({"bound": "valu-fp32" if variant == 16 else "valu-fp64", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": min(1.0, ach / peak), "flops_per_sample": f_sample,
+                "d4_fraction": d4_fraction if d4_fraction is not None else "not measured for this scene: the 3 N_{D4>=0} term is left out",
+                "traffic": (replay or {}).get("traffic"), "traffic_source": (replay or {}).get("traffic_source"),
+                "hbm": ({"achieved": alg_bytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / t / 1e9 / PEAK_HBM_GBS,
+                         "algorithmic_bytes_per_launch": alg_bytes} if alg_bytes else None)})
+    if peak_measured and variant != 16:
+        out["frac_of_measured_peak"] = min(1.0, ach / peak_measured)
+    return out
+
+
 # Issue cost of a wave64 VALU instruction per class, in cycles of the SIMD it occupies, from the wall-clock price list
 # of profiles/ubench/fp64_peak.hip (profiles/r3/fp64_peak.txt: ns per wave-instruction per SIMD relative to v_fma_f64 = 4
 # cycles: fp64 add/mul/fma/min/ldexp/compare, v_cndmask_b32 with an SGPR mask, conversions, 64-bit moves, v_mul_lo/hi_u32
@@ -146,10 +222,43 @@ def valu_issue_view(pmc, source):
             "measured_in_run": False, "source": source}
 
 
-def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
-    """BASELINE configs[1], configs[4] (the full frame through the grid kernel, a strip — the full frame with
-    --full-c5-exhaustive — through the exhaustive pipeline), the plane scene and the two labelled rows, measured in this run, outside the timed region.  Every group of rows stands alone: a failure is
-    recorded under its name and the others are still measured."""
+def replayed_profile(name):
+    """PMC-derived figures of a committed rocprofv3 pass of the same command (profiles/prof_*.sh), newest round first."""
+    for rnd in ("r4", "r3"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            return json.load(open(path)), f"profiles/{rnd}/{name}"
+    return None, None
+
+
+def grid_replay():
+    gj, src = replayed_profile("c5_grid_pmc_summary.json")
+    if not gj:
+        return None
+    out = {}
+    if "FETCH_SIZE" in gj and "WRITE_SIZE" in gj:
+        out["traffic"] = 1024.0 * sum(gj.get(k, 0.0) for k in ("FETCH_SIZE", "WRITE_SIZE", "grid_finalize.FETCH_SIZE",
+                                                                 "grid_finalize.WRITE_SIZE"))
+        out["traffic_source"] = {"measured_in_run": False, "file": src,
+                                 "note": "FETCH_SIZE + WRITE_SIZE per frame, render_grid_kernel + grid_finalize_kernel (rocprofv3 "
+                                         "--pmc, separate passes; profiles/prof_c5_grid.sh)"}
+    if "SQ_INSTS_VALU" in gj and "GRBM_GUI_ACTIVE" in gj:
+        cyc = gj["GRBM_GUI_ACTIVE"] / 8.0
+        busy = gj.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / cyc
+        lanes = gj.get("SQ_THREAD_CYCLES_VALU", 0.0) / gj["SQ_INSTS_VALU"] / 64.0
+        out["valu_issue"] = {"valu_busy_hw": busy, "active_lanes_frac": lanes, "busy_x_active_lanes": busy * lanes,
+                             "wave_instructions_per_launch": gj["SQ_INSTS_VALU"], "measured_in_run": False, "source": src,
+                             "note": "the share of the VALU's lane-slots that do work: what bounds this kernel (divergent walks, "
+                                     "per-lane gathers), next to an L2 hit rate of " + (f"{gj['l2_hit_rate']:.2f}" if "l2_hit_rate" in gj else "?")}
+    out["grid_bytes"] = gj.get("grid_bytes", 22.0e6)
+    return out
+
+
+def other_configs(rtm, cfg, device, host_trig, full_c5=True, cpu_rows=64, d4_cornell=None, peak_measured=None):
+    """BASELINE configs[1], configs[4] (the full frame through the grid kernel AND through the exhaustive pipeline), the
+    plane scene and the labelled rows, measured in this run, outside the timed region.  EVERY row carries its own roofline
+    object (roofline_of: the work model follows the kernel the library reports).  Every group of rows stands alone: a
+    failure is recorded under its name and the others are still measured."""
     import torch
     out = {"measured_in_run": True}
 
@@ -161,8 +270,17 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
             r.render_rows_device(want=("f32",), stats=False, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        _, st = r.render_rows_device(want=("f32",), stats=True, **kw)
+        o, st = r.render_rows_device(want=("f32",), stats=True, **kw)
+        st["pixels"] = int(o["f32"].shape[0]) * int(o["f32"].shape[1])
         return dt, st
+
+    def row_of(dt, st, steps, n_objects, width, d4=None, replay=None, **extra):
+        row = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": steps,
+               "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
+               "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"],
+               "roofline": roofline_of(st, st["kernel_ms"], n_objects, width, d4, peak_measured, replay)}
+        row.update(extra)
+        return row
 
     def guarded(name, fn):
         try:
@@ -176,9 +294,7 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
         for name, mb in (("c2_cornell_512x512_256spp_max8", 8), ("c2_cornell_512x512_256spp_unlimited", -1)):
             r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=cfg["seed"], device=device, host_trig=host_trig)
             dt, st = timed(r, 5)
-            out[name] = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 5,
-                         "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-                         "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"]}
+            out[name] = row_of(dt, st, 5, len(data.object), 512, d4_cornell)
 
     def headline_data():
         data = rtm.LoadData(os.path.join(ROOT, "scenes", "cornellBoxSetting.json")).data
@@ -188,14 +304,43 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
     def reuse_row():
         # SEPARATELY LABELLED row: the headline frame with the primary hit of a sub-pixel computed once
         # for its S samples (variant 15) — same image and counters, less work per sample than the reference does
-        r = rtm.Renderer(headline_data(), mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+        data = headline_data()
+        r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
                          host_trig=host_trig, variant=15)
         dt, st = timed(r, 3)
-        out["LABELLED_headline_frame_with_primary_hit_reuse"] = {
-            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-            "kernel_ms": st["kernel_ms"], "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-            "note": "not comparable with the headline value or the CPU baseline: one nearest-hit search per sub-pixel "
-                    "instead of one per sample for the primary ray (the reference repeats it, src/Renderer.cpp:224-238)"}
+        out["LABELLED_headline_frame_with_primary_hit_reuse"] = row_of(
+            dt, st, 3, len(data.object), cfg["width"], d4_cornell,
+            note="not comparable with the headline value or the CPU baseline: one nearest-hit search per sub-pixel instead of one "
+                 "per sample for the primary ray (the reference repeats it, src/Renderer.cpp:224-238); its roofline prices the "
+                 "reference's flops, which this row does not all execute")
+
+    def tolerance_row():
+        # SEPARATELY LABELLED row: the default kernel's source compiled with FMA contraction and one-ulp division / square
+        # root (variant 18, csrc/rtm_kernels_tol.hip) — north_star's tolerance is 1e-4 per pixel, the default kernels meet
+        # it with 0.  Reported with its pixel differences against the exact frame of this run and its own roofline.
+        data = headline_data()
+        exact, est = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+                                  host_trig=host_trig).render_rows_device(want=("f64",), stats=True)
+        r = rtm.Renderer(data, mode="repaired", max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=device,
+                         host_trig=host_trig, variant=18)
+        tol, _ = r.render_rows_device(want=("f64",), stats=True)
+        a, b = exact["f64"], tol["f64"]
+        delta = (a - b).abs()
+        differing = int((a.view(torch.int64) != b.view(torch.int64)).any(dim=2).sum())
+        outside = int((delta.amax(dim=2) > 1e-4).sum())
+        del exact, tol
+        dt, st = timed(r, 5)
+        vj, vsrc = replayed_profile("tolerance_pmc_summary.json")
+        out["LABELLED_headline_frame_fp64_tolerance"] = row_of(
+            dt, st, 5, len(data.object), cfg["width"], d4_cornell,
+            pixels_that_differ_from_the_exact_frame=differing, pixels_outside_1e_4=outside, max_abs_delta=float(delta.max()),
+            counters_equal_the_exact_kernels=all(st[k] == est[k] for k in ("casts", "bounces", "draws")),
+            executed_valu_wave_instructions=({"value": vj["SQ_INSTS_VALU"], "measured_in_run": False, "source": vsrc} if vj else None),
+            note="the same kernel source with FMA contraction and division / square root to about one ulp; float islands, RNG, "
+                 "roulette thresholds, the unfused fold and the order of the additions kept; primary rays (shared by the S "
+                 "samples of a sub-pixel) keep the reference's bits and their exact ties — the Cornell box's wall seams project "
+                 "onto the image's diagonals — are settled with the reference's arithmetic.  Asserted <= 1e-4 per pixel against "
+                 "the exact frame in tests/test_tolerance_gpu.py; the bit-exact kernel stays the default")
 
     def fp32_row():
         # SEPARATELY LABELLED row: single precision with the hardware's sqrt / sin / cos (variant 16) — not a parity path;
@@ -207,13 +352,12 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
         fast_frame, _ = r.render_rows_device(want=("f32",), stats=True)
         dt, st = timed(r, 3)
         delta = (fast_frame["f32"].double() - exact_frame["f32"].double()).abs()
-        out["LABELLED_headline_frame_fp32_fast_NOT_PARITY"] = {
-            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-            "kernel_ms": st["kernel_ms"], "dtype": "f32", "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-            "pixels_outside_1e-4_of_the_fp64_frame": float((delta.amax(dim=2) > 1e-4).double().mean()),
-            "max_abs_delta": float(delta.max()), "mean_abs_delta": float(delta.mean()),
-            "note": "float arithmetic, v_sqrt/v_rsq/v_sin/v_cos, fused multiply-adds, forward throughput: a sample whose ray "
-                    "grazes a silhouette may take another path than the reference's; not comparable with the headline value"}
+        out["LABELLED_headline_frame_fp32_fast_NOT_PARITY"] = row_of(
+            dt, st, 3, len(data.object), cfg["width"], d4_cornell, dtype="f32",
+            **{"pixels_outside_1e-4_of_the_fp64_frame": float((delta.amax(dim=2) > 1e-4).double().mean())},
+            max_abs_delta=float(delta.max()), mean_abs_delta=float(delta.mean()),
+            note="float arithmetic, v_sqrt/v_rsq/v_sin/v_cos, fused multiply-adds, forward throughput: a sample whose ray "
+                 "grazes a silhouette may take another path than the reference's; not comparable with the headline value")
 
     def plane_room():
         # scenes/planeRoom.json (png::PlaneObject completed as a finite square) at 1080p x 256 spp: the chunked
@@ -222,11 +366,10 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
         room.width, room.height, room.samples, room.superSamples = 1920, 1080, 16, 4
         r = rtm.Renderer(room, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
         dt, st = timed(r, 3)
-        out["plane_room_1080p_256spp_max8"] = {
-            "value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-            "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-            "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(), "split": st["split"],
-            "note": "6 planes + 2 spheres; not a reference scene (the reference's PlaneObject::Intersect is unfinished)"}
+        out["plane_room_1080p_256spp_max8"] = row_of(
+            dt, st, 3, len(room.object), 1920, None,
+            note="6 planes + 2 spheres; not a reference scene (the reference's PlaneObject::Intersect is unfinished); the "
+                 "roofline prices every object at a sphere's 17 flops per test")
 
     def c5():
         stress = rtm.make_stress_scene(n=100_000, seed=12345)
@@ -236,23 +379,14 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
         # tens of Intersect calls instead of 100 000
         r = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig)
         dt, st = timed(r, 3)
-        row = {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 3,
-               "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-               "variant": rtm.lib().rtm_variant_name(st["variant"]).decode(),
-               "note": ("the nearest hit of the reference's loop over all 100 000 spheres (src/Renderer.cpp:58-73) found "
-                        "through a uniform grid: 15.7 sphere tests per cast instead of 100 000 (profiles/r3/grid_occupancy.txt), "
-                        "the same hit object, distance and image; the row below is the exhaustive kernel")}
-        gpath = os.path.join(ROOT, "profiles", "r3", "c5_grid_pmc_summary.json")
-        if os.path.exists(gpath):
-            gj = json.load(open(gpath))
-            if "FETCH_SIZE" in gj and "WRITE_SIZE" in gj:
-                row["traffic"] = 1024.0 * sum(gj.get(k, 0.0) for k in ("FETCH_SIZE", "WRITE_SIZE", "grid_finalize.FETCH_SIZE",
-                                                                        "grid_finalize.WRITE_SIZE"))
-                row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_grid_pmc_summary.json",
-                                         "note": "FETCH_SIZE + WRITE_SIZE per frame, render_grid_kernel + grid_finalize_kernel "
-                                                 "(rocprofv3 --pmc, separate passes; profiles/prof_c5_grid.sh): the per-sample "
-                                                 "terms written once and read once (2 x 17 GB) and the L2 misses of the 22 MB "
-                                                 "of cell lists, served mostly by the Infinity Cache"}
+        # the sphere tests the walks make: one more render of the same frame with the counting instantiation
+        _, cst = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig,
+                              count_tests=True).render_rows_device(want=("f32",), stats=True)
+        if cst["casts"] == st["casts"]:
+            st["object_tests"] = cst["object_tests"]
+        row = row_of(dt, st, 3, 100_000, 1920, None, grid_replay(),
+                     note="the nearest hit of the reference's loop over all 100 000 spheres (src/Renderer.cpp:58-73) found "
+                          "through a uniform grid: the same hit object, distance and image; the rows below are the exhaustive kernel")
         if cpu_rows > 0:
             # the CPU port beside it (timed on a crop and scaled — the reference's loop makes 100 000
             # Intersect calls per cast): a 96x96 block of pixels in the middle of the frame at 4 spp, every host core
@@ -261,8 +395,8 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
             import numpy as np
             crop = rtm.make_stress_scene(n=100_000, seed=12345)
             crop.width, crop.height, crop.samples, crop.superSamples = 1920, 1080, 4, 1
-            cst, carr, cn = crop.to_c()
-            ost = _oracle.Settings.from_buffer_copy(bytes(cst))
+            cst_, carr, cn = crop.to_c()
+            ost = _oracle.Settings.from_buffer_copy(bytes(cst_))
             oarr = (_oracle.Sphere * cn).from_buffer_copy(bytes(carr))
             xy = np.stack(np.meshgrid(np.arange(912, 1008), np.arange(492, 588)), axis=-1).reshape(-1, 2).astype(np.int32)
             threads = _oracle.lib().rtmo_max_threads()
@@ -276,36 +410,30 @@ def other_configs(rtm, cfg, device, host_trig, full_c5=False, cpu_rows=64):
         out["c5_stress_100k_full_1080p_256spp"] = row
 
         # the exhaustive large-scene pipeline (variant 12: every cast tests all 100 000 spheres, packed-fp32 rejection
-        # in front of the exact test) on a strip; the whole frame takes ~24 s (--full-c5-exhaustive)
+        # in front of the exact test): a strip, and the whole frame (~24 s) — the path north_star names for configs[4]
         rx = rtm.Renderer(stress, mode="repaired", max_bounces=8, seed=cfg["seed"], device=device, host_trig=host_trig,
                           variant=12)
         rx.render_rows_device(508, 516, want=("f32",), stats=True)  # warm: buffers
 
-        def c5_row(lo, hi):
+        def c5_row(lo, hi, replay=None):
             t0 = time.perf_counter()
-            _, st = rx.render_rows_device(lo, hi, want=("f32",), stats=True)
+            o, st = rx.render_rows_device(lo, hi, want=("f32",), stats=True)
             dt = time.perf_counter() - t0
-            tests_per_s = st["casts"] * 100_000 / dt
-            return {"value": st["samples"] / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "steps": 1,
-                    "kernel_ms": st["kernel_ms"], "casts_per_sample": st["casts"] / st["samples"],
-                    "sphere_tests_per_s": tests_per_s,
-                    "frac_of_packed_fp32_peak_at_16_flops_per_test": tests_per_s * 16.0 / 1e12 / PEAK_FP32_VECTOR_TFLOPS,
-                    "variant": rtm.lib().rtm_variant_name(st["variant"]).decode()}
+            st["pixels"] = int(o["f32"].shape[0]) * int(o["f32"].shape[1])
+            return row_of(dt, st, 1, 100_000, 1920, None, replay)
         row = c5_row(508, 572)
         row["note"] = ("a 64-row strip: 122 880 rays per trip, the sphere list cut into 8 parts so that rays x parts fill the "
                        "chip (DESIGN.md §4)")
         out["c5_stress_100k_exhaustive_rows_508_572_of_1080p_256spp"] = row
         if full_c5:
-            row = c5_row(0, 1080)
-            row["traffic"] = None
-            tpath = os.path.join(ROOT, "profiles", "r3", "c5_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                row["traffic"] = tj["bytes_per_frame"]
-                row["traffic_source"] = {"measured_in_run": False, "file": "profiles/r3/c5_traffic.json", "note": tj.get("note")}
-            out["c5_stress_100k_exhaustive_full_1080p_256spp"] = row
+            replay = None
+            tj, tsrc = replayed_profile("c5_traffic.json")
+            if tj:
+                replay = {"traffic": tj["bytes_per_frame"], "traffic_source": {"measured_in_run": False, "file": tsrc, "note": tj.get("note")}}
+            out["c5_stress_100k_exhaustive_full_1080p_256spp"] = c5_row(0, 1080, replay)
 
     guarded("c2_cornell_512x512_256spp", c2)
+    guarded("LABELLED_headline_frame_fp64_tolerance", tolerance_row)
     guarded("LABELLED_headline_frame_with_primary_hit_reuse", reuse_row)
     guarded("LABELLED_headline_frame_fp32_fast_NOT_PARITY", fp32_row)
     guarded("plane_room_1080p_256spp_max8", plane_room)
@@ -372,9 +500,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip with_d2h and other_configs")
     ap.add_argument("--no-full-c5", action="store_true", help="(kept for old command lines: the full frame of the 100k-sphere "
                                                               "scene is a quarter of a second through the grid kernel)")
-    ap.add_argument("--full-c5-exhaustive", action="store_true",
-                    help="other_configs: also render the full 1080p x 256 spp frame of the 100k-sphere scene through the "
-                         "exhaustive pipeline (variant 12, ~24 s); its 64-row strip is always measured")
+    ap.add_argument("--full-c5-exhaustive", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-full-c5-exhaustive", action="store_true",
+                    help="other_configs: skip the full 1080p x 256 spp frame of the 100k-sphere scene through the exhaustive "
+                         "pipeline (variant 12, ~24 s: the path north_star names for configs[4]); its 64-row strip is always "
+                         "measured")
     ap.add_argument("--layout", default="bands", choices=["bands", "strips"],
                     help="N > 1: interleaved 8-row bands (default) or contiguous row strips per rank")
     ap.add_argument("--ab", type=str, default="", help="comma-separated variants: interleaved A/B rounds, kernel ms each")
@@ -517,6 +647,7 @@ def main():
 
     dog.enter("all_reduce(MAX) of the ranks' times")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    kernel_ms_local = kernel_ms
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if use_group:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -537,6 +668,14 @@ def main():
         barrier()
         with_d2h = time.perf_counter() - t1
 
+    # an N-rank line proves itself, outside the timed region: the assembled frame against rank 0's own
+    # single-launch render bit for bit, every rank's kernel time / rows / counters, the gather alone timed
+    evidence = None
+    if use_group:
+        dog.enter("multi-GPU evidence: per-rank stats, the gather alone, rank 0's single-GPU frame", 30 * args.stage_timeout)
+        from raytracingmin_amd.distributed import multi_gpu_evidence
+        evidence = multi_gpu_evidence(sr, stats, kernel_ms_local, args.steps, barrier, use_group=True)
+
     total_samples = cfg["width"] * (row_hi - row_lo) * spp
     value = total_samples * args.steps / elapsed / 1e6
 
@@ -553,25 +692,48 @@ def main():
                 d4 = cpu["d4_fraction"]
             except Exception as exc:  # the headline line must come out whatever an extra does; the failure is named in it
                 cpu, extras_failed = None, {"cpu_baseline": repr(exc)}
-        f_sample = algorithmic_flops_per_sample(n_spheres, cps, bps, d4)
-        rank_samples = stats["samples"]  # samples one launch of this rank processed
-        flops_per_launch = f_sample * rank_samples
-        achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        extras_failed = dict(extras_failed)
+        pk = None
+        if world == 1 and not args.no_extras:
+            try:
+                pk = measured_fp64_peak(rtm)
+            except Exception as exc:
+                extras_failed["peak_measured"] = repr(exc)
         rows0 = stats["samples"] // (cfg["width"] * spp)  # rows this rank's launch stores
-        alg_bytes = rows0 * cfg["width"] * 12 + n_spheres * 96
-        hbm_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        stats["pixels"] = rows0 * cfg["width"]
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         headline = args.workload == "c3" and not args.rows and \
             all(cfg[k] == HEADLINE[k] for k in ("width", "height", "samples", "super_samples", "max_bounces"))
+        replay = None
         if world == 1 and headline and args.variant == 0 and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic = tj["bytes_per_launch"]  # PMC bytes of a committed rocprofv3 --pmc pass of this command
-            traffic_src = {"measured_in_run": False, "file": "profiles/latest_traffic.json",
-                           "profile": tj.get("source", "profiles/r1/default_pmc_summary.json"),
-                           "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes",
-                           "note": tj.get("note")}
+            replay = {"traffic": tj["bytes_per_launch"],  # PMC bytes of a committed rocprofv3 --pmc pass of this command
+                      "traffic_source": {"measured_in_run": False, "file": "profiles/latest_traffic.json",
+                                         "profile": tj.get("source", "profiles/r1/default_pmc_summary.json"),
+                                         "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes",
+                                         "note": tj.get("note")}}
+        if stats["variant"] == 17:
+            replay = grid_replay()
+            if world == 1 and not args.no_extras:  # the walks' sphere tests: one counting render of this rank's rows
+                try:
+                    from raytracingmin_amd.renderer import Renderer
+                    _, cst = Renderer(data, mode=cfg["mode"], max_bounces=cfg["max_bounces"], seed=cfg["seed"], device=local_rank,
+                                      host_trig=host_trig, count_tests=True).render_rows_device(row_lo, row_hi, want=("f32",), stats=True)
+                    if cst["casts"] == stats["casts"]:
+                        stats["object_tests"] = cst["object_tests"]
+                except Exception as exc:
+                    extras_failed["object_tests"] = repr(exc)
         resolved = rtm.lib().rtm_variant_name(stats["variant"]).decode()  # what the library ran (rtm_stats.variant)
+        # the Cornell scenes' D4 >= 0 share comes from this run's oracle sample; other scenes' is not measured
+        d4_here = None if args.workload == "c5" else d4
+        roof = roofline_of(stats, kernel_ms, n_spheres, cfg["width"], d4_here, pk["value"] if pk else None, replay)
+        roof["achieved_source"] = {"measured_in_run": True, "what": "the work model of the kernel the library reports "
+                                   "(rtm_stats.variant; roofline_of in bench.py) x this run's kernel counters / HIP-event kernel time"}
+        if roof["bound"] == "valu-fp64":
+            roof["note"] = ("no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM traffic; peak counts FMA as 2 "
+                            "flops" + ("; this is the labelled tolerance row, compiled with contraction" if stats["variant"] == 18 else
+                                       " but parity forbids contraction, so the attainable ceiling is <= 0.5"))
         line = {
             "metric": "Msamples/s (W*H*spp/s), Cornell box 1080p@1024spp" if args.workload == "c3" else
                       f"Msamples/s (W*H*spp/s), BASELINE configs workload {args.workload}", "value": value,
@@ -587,46 +749,22 @@ def main():
                        "variant": resolved, "sample_split_waves_per_tile": stats["split"],
                        "collective": (f"{backend} gather, {world} rank(s)" if use_group else "none (one rank, frame stays in HBM)"),
                        "casts_per_sample": cps, "bounces_per_sample": bps},
-            "roofline": {
-                "bound": "valu-fp64", "achieved": achieved_tflops, "peak": PEAK_FP64_VECTOR_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP64_VECTOR_TFLOPS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "achieved_source": {"measured_in_run": True, "what": "flops_per_sample (casts and bounces from this run's kernel "
-                                    "counters, D4>=0 fraction from this run's oracle sample) x samples / HIP-event kernel time"},
-                "kernel": "render_tiles_kernel" if n_spheres <= 256 else "wf_nearest_f32_kernel + wf_shade_kernel",
-                "kernel_ms": kernel_ms,
-                "flops_per_sample": f_sample,
-                "note": "no MFMA and not HBM-bound: ~1 kflop fp64 per sample vs 0.012 B of HBM "
-                        "traffic; peak counts FMA as 2 flops but parity forbids contraction, so the "
-                        "attainable ceiling is <= 0.5",
-                "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": hbm_gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes},
-            },
+            "roofline": roof,
         }
-        ppath = next((q for q in (os.path.join(ROOT, "profiles", "r3", "default_pmc_summary.json"),
+        if evidence is not None:
+            line["frame_matches_single_gpu"] = evidence["frame_matches_single_gpu"]
+            line["gather_ms"] = evidence["gather_ms"]
+            line["config"]["per_rank"] = evidence["per_rank"]
+            line["config"]["multi_gpu_evidence"] = {k: evidence[k] for k in ("totals", "kernel_ms_slowest_over_mean", "how")}
+        ppath = next((q for q in (os.path.join(ROOT, "profiles", "r4", "default_pmc_summary.json"),
+                                  os.path.join(ROOT, "profiles", "r3", "default_pmc_summary.json"),
                                   os.path.join(ROOT, "profiles", "r2", "default_pmc_summary.json"),
                                   os.path.join(ROOT, "profiles", "r1", "default_pmc_summary.json")) if os.path.exists(q)), "")
         if world == 1 and headline and args.variant == 0 and ppath:
             line["roofline"]["valu_issue"] = valu_issue_view(json.load(open(ppath)), os.path.relpath(ppath, ROOT))
-        if world == 1 and not args.no_extras:
-            try:
-                pk = measured_fp64_peak(rtm)
-                line["roofline"]["peak_measured"] = pk
-                line["roofline"]["frac_of_measured_peak"] = achieved_tflops / pk["value"]
-            except Exception as exc:
-                extras_failed["peak_measured"] = repr(exc)
+        if pk is not None:
+            line["roofline"]["peak_measured"] = pk
             line["roofline"]["peak_source"] = "AMD datasheet, FP64 vector 78.6 TFLOP/s (MI355X_MICROARCH.md lists fp32 157.3 only)"
-        if n_spheres >= 512 and args.variant in (0, 12):
-            # large scenes: nearly every (ray, sphere) pair is settled by the single-precision rejection
-            # test (8 packed-fp32 FMAs = 16 flops), so the binding roof is the fp32 vector ALU
-            tests_per_s = stats["casts"] * n_spheres / (kernel_ms * 1e-3)
-            ach = tests_per_s * 16.0 / 1e12
-            line["roofline"].update({
-                "bound": "valu-fp32", "achieved": ach, "peak": PEAK_FP32_VECTOR_TFLOPS, "frac": ach / PEAK_FP32_VECTOR_TFLOPS,
-                "sphere_tests_per_s": tests_per_s, "algorithmic_fp64_tflops": achieved_tflops,
-                "note": "brute force over every sphere; a pair whose discriminant is provably negative is rejected "
-                        "by 8 packed-fp32 FMAs (16 flops, counted here), the rest get the reference's fp64 "
-                        "arithmetic; algorithmic_fp64_tflops prices every pair at the reference's 17 flops"})
         if cpu is not None:
             # the oracle is a restatement ("port"); what it is worth against the genuine compiled reference was
             # measured once in the build container (the GPU box never sees /root/reference): DESIGN.md §8
@@ -642,7 +780,9 @@ def main():
                                         "(SURVEY.md §8d wall time = kernel + final D2H/gather); not the headline value"}
         if world == 1 and not args.no_extras and headline:
             try:
-                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=args.full_c5_exhaustive, cpu_rows=args.cpu_rows)
+                line["other_configs"] = other_configs(rtm, cfg, local_rank, host_trig, full_c5=not args.no_full_c5_exhaustive,
+                                                      cpu_rows=args.cpu_rows, d4_cornell=(cpu["d4_fraction"] if cpu else None),
+                                                      peak_measured=(pk["value"] if pk else None))
             except Exception as exc:
                 extras_failed["other_configs"] = repr(exc)
         if extras_failed:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTM_ABI_VERSION 4
+#define RTM_ABI_VERSION 5
 
 typedef enum rtm_status {
     RTM_OK = 0,
@@ -105,7 +105,11 @@ enum { RTM_MODE_LITERAL = 0,  /* L0: HEAD as shipped (normal lost, recursion get
         * all on both sides (a fraction of a second, once per device) and keeps the one-ulp
         * differences in a 4 MB table.  Costs ~2 % of a frame; makes GPU and CPU-libm renders agree
         * bit for bit even where one-ulp differences are amplified over many bounces.            */
-       RTM_MODE_HOST_TRIG = 0x100 };
+       RTM_MODE_HOST_TRIG = 0x100,
+       /* flag, OR-ed into mode (diagnostic): a render WITH rtm_stats also counts the Intersect evaluations it makes
+        * (rtm_stats.object_tests).  The exhaustive kernels make n_objects per cast by construction; the uniform-grid kernel
+        * (variant 17) runs a counting instantiation that is a few per cent slower, so time a frame without the flag.     */
+       RTM_MODE_COUNT_TESTS = 0x200 };
 
 typedef struct rtm_options {
     int32_t mode;         /* RTM_MODE_*                                                        */
@@ -133,6 +137,8 @@ typedef struct rtm_stats {
     int32_t variant;      /* the kernel variant that ran (rtm_options.variant resolved; see
                              rtm_variant_name), and                                              */
     int32_t split;        /* waves per 8x8 tile of the sample split (1 = not split)            */
+    uint64_t object_tests; /* Object::Intersect evaluations (src/Renderer.cpp:66): casts x n_objects for the
+                             exhaustive kernels; for the uniform-grid kernel the count of RTM_MODE_COUNT_TESTS, else 0 */
 } rtm_stats;
 
 /* A scene flattened to the kernels' layout and resident on one device (opaque).  Created once,
@@ -161,11 +167,22 @@ int rtm_output_rows(const rtm_options* options);
  * 1.6 GB for the headline frame, capped at 24 GiB per stream (a launch whose terms would not fit splits fewer
  * tiles, or none), and in-wave sample stealing 1.8 KiB x (2 sqrt(spp) + 5) per whole tile (3.8 GB for the headline
  * frame; without room the launch runs without it); unlimited-depth renders keep two pooled record stacks per lane
- * (5.5 GB for a 1080p frame); the large-scene grid kernel 24 B per sample of a launch (12.7 GB for a 1080p frame at
- * 256 spp; beyond 16 GiB, or what the device gives, the frame is rendered in several launches); the exhaustive
+ * (5.5 GB for a 1080p frame); the large-scene grid kernel 32 B per sample of a launch (17.0 GB for a 1080p frame at
+ * 256 spp: above the 16 GiB budget, so that frame is rendered in two launches — beyond the budget, or what the device
+ * gives, a frame is cut into several launches of as many tiles as fit); the exhaustive
  * large-scene pipeline ~300 B per pixel plus 4 B per pixel and record level. */
 int rtm_release_scratch(int device);
-/* The same for ONE stream: waits for that stream's queued work, frees the buffers and the sticky status word the
+/* What a render with these arguments will ask of those work buffers, in bytes, before anything is allocated:
+ * out_bytes[0] the total, [1] per-sample terms (sample split of a launch's last tiles / the grid kernel's term buffer:
+ * one launch's worth, at most the 16 GiB budget), [2] pooled hit records (unlimited depth or a cap of 16 and more),
+ * [3] the exhaustive large-scene pipeline's path state, [4] the rows of in-wave sample stealing.  The buffers are per
+ * (device, stream), grown on demand and kept until rtm_release_scratch / rtm_stream_release; a stream that has rendered
+ * larger frames already holds more.  Where the device cannot give an OPTIONAL buffer (terms, stolen rows) the render
+ * runs without the feature or in more launches — same image. */
+int rtm_scratch_bytes(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options,
+                      uint64_t out_bytes[5]);
+/* The same for ONE stream: waits for that stream's queued work (and, like rtm_release_scratch, for every render call
+ * that is being enqueued at that moment), frees the buffers and the sticky status word the
  * library keeps for (device, stream) and forgets the pair.  Call it before destroying a stream that has rendered
  * (a later stream may be given the same handle and would inherit the context otherwise).  An overflow that was
  * never reported is returned here (RTM_ERR_UNSUPPORTED), like rtm_stream_status would. */

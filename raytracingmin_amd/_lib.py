@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("RTM_LIB_OVERRIDE") or os.path.join(_HERE, "librtm_hip
 RTM_OK = 0
 MODE_LITERAL, MODE_REPAIRED = 0, 1
 MODE_HOST_TRIG = 0x100  # flag: sin/cos exactly as the host libm returns them (include/rtm.h)
+MODE_COUNT_TESTS = 0x200  # flag: count Intersect evaluations into rtm_stats.object_tests (diagnostic)
 MODES = {"literal": MODE_LITERAL, "repaired": MODE_REPAIRED, 0: 0, 1: 1}
 
 
@@ -54,13 +55,13 @@ class rtm_options(C.Structure):
 class rtm_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("casts", C.c_uint64), ("bounces", C.c_uint64),
                 ("draws", C.c_uint64), ("kernel_ms", C.c_double), ("variant", C.c_int32),
-                ("split", C.c_int32)]
+                ("split", C.c_int32), ("object_tests", C.c_uint64)]
 
     def as_dict(self):
         return {"samples": int(self.samples), "casts": int(self.casts),
                 "bounces": int(self.bounces), "draws": int(self.draws),
                 "kernel_ms": float(self.kernel_ms), "variant": int(self.variant),
-                "split": int(self.split)}
+                "split": int(self.split), "object_tests": int(self.object_tests)}
 
 
 # every symbol include/rtm.h declares: name -> (restype, argtypes)
@@ -73,6 +74,7 @@ SIGNATURES = {
     "rtm_output_rows": (C.c_int, [_P(rtm_options)]),
     "rtm_release_scratch": (C.c_int, [C.c_int]),
     "rtm_stream_release": (C.c_int, [C.c_int, C.c_void_p]),
+    "rtm_scratch_bytes": (C.c_int, [_P(rtm_settings), C.c_void_p, _P(rtm_options), _P(C.c_uint64)]),
     "rtm_num_variants": (C.c_int, []),
     "rtm_variant_name": (C.c_char_p, [C.c_int]),
     "rtm_scene_create": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _P(C.c_void_p)]),
@@ -126,7 +128,7 @@ DEBUG_SIGNATURES = {
     "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_double)]),
 }
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

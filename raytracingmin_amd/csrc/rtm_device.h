@@ -5,7 +5,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace rtm {
+// The kernel headers (this one, rtm_path.h, rtm_render_kernel.h) are compiled twice: into namespace rtm by rtm_kernels.hip
+// (-ffp-contract=off, correctly rounded division and square root sequences: the bit-exact kernels) and into namespace
+// rtm_tol by rtm_kernels_tol.hip (-DRTM_TOL=1, FMA contraction on, division and square root to about one ulp: the
+// LABELLED tolerance row, variant 18 — same loop nest, RNG, thresholds, float islands and order of additions).
+#ifndef RTM_NS
+#define RTM_NS rtm
+#endif
+#ifndef RTM_TOL
+#define RTM_TOL 0
+#endif
+
+namespace RTM_NS {
 
 struct D3 {
     double x, y, z;
@@ -19,6 +30,13 @@ __device__ __forceinline__ D3 operator*(D3 a, D3 b) { return D3{a.x * b.x, a.y *
 __device__ __forceinline__ D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ D3 operator/(D3 a, double s) { return D3{a.x / s, a.y / s, a.z / s}; }
 
+// One level of the recursion's unwinding, L = colorKD * L_next + emission (src/Renderer.cpp:109), as a separate multiply
+// and add WHATEVER the translation unit's contraction mode: a sample's radiance — and with it the image — is then a
+// function of the path's hit ids alone in the tolerance build too (rtm_kernels_tol.hip), bit for bit.
+__device__ __forceinline__ D3 fold_step(const D3 c, const D3 L, const D3 e) {
+#pragma clang fp contract(off)
+    return D3{c.x * L.x + e.x, c.y * L.y + e.y, c.z * L.z + e.z};
+}
 // src/Ray.h:61-63
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // src/Ray.h:64-66 (middle component is (-a.x)*b.z + a.z*b.x)
@@ -256,4 +274,4 @@ __host__ __device__ __forceinline__ double rng_u01_at(uint64_t seed_mult, uint32
     return rng_next(s);
 }
 
-}  // namespace rtm
+}  // namespace RTM_NS

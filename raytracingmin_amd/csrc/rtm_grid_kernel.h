@@ -46,7 +46,9 @@ __device__ __forceinline__ unsigned grid_tile_of_block(const RenderParams& P, un
 }
 
 // blockIdx.x: index into this launch's tiles [tile_base, tile_base + gridDim.x); terms: P.contrib, gridDim.x tiles
-template <typename RecT, int LDS_D>
+//   COUNT   (RTM_MODE_COUNT_TESTS) the walks count their Intersect evaluations into P.counters[4]: the measurement
+//           bench.py's rows of this kernel carry (sphere tests per cast); the timed steps run the plain instantiation
+template <typename RecT, int LDS_D, bool COUNT = false>
 __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(const RenderParams P, const unsigned tile_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -104,9 +106,10 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
         return true;
     };
     bool busy = take_unit();
-    GridWalk<MathFast, SceneGlobal> walk;
+    GridWalk<MathFast, SceneGlobal, COUNT> walk;
     walk.attach_queue(queue, 64, lane);
     bool walking = false;
+    [[maybe_unused]] unsigned long long n_tests = 0;
     while (__builtin_amdgcn_ballot_w64(busy) != 0) {  // wave-uniform
         if (busy && !walking) walking = walk.begin(sc, org, dir);
         for (;;) {
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
         }
         if (busy && !walking) {
             RTM_GRID_OCC(8);
+            if constexpr (COUNT) n_tests += walk.tests;
             D3 term;
             bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
             if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
@@ -146,6 +150,11 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
         wave_add_counter(P.counters + 1, pc.bounces);
         wave_add_counter(P.counters + 2, pc.draws);
         if (stack.overflow) atomicOr(P.counters + 3, 1ull);
+        if constexpr (COUNT) {
+            unsigned long long t = n_tests;
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0) atomicAdd(P.counters + 4, t);
+        }
     }
 }
 

@@ -28,6 +28,7 @@ int intersect_objects_batch(const rtm_object* objs, const double* org, const dou
 int scene_destroy(rtm_scene* sc);
 size_t scene_size(const rtm_scene* sc);
 int stream_status(int device, void* stream);
+int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[5]);
 int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
                  uint8_t* out8, void* stream, rtm_stats* stats);
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int spheres_on_device,
@@ -54,6 +55,9 @@ int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads
                     uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap);
 int fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms);
 int math_probe(int op, const double* a, const double* b, size_t n, double* out);
+// the labelled tolerance row (rtm_kernels_tol.hip): launches for a planned rtm::RenderParams passed by bytes
+int launch_tol(const void* render_params, size_t params_bytes, unsigned grid, size_t lds_pad, void* stream);
+int tol_math_probe(int op, const double* a_dev, const double* b_dev, size_t n, double* out_dev);  // ops 32.. of math_probe
 
 // host side (rtm_scene.cpp, rtm_image.cpp)
 int scene_parse_json(const char* text, size_t len, int literal_loader, rtm_settings* st,

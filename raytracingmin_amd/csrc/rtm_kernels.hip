@@ -47,6 +47,7 @@ namespace rtm {
 // ================================================================================================
 // Host side of the device path
 // ================================================================================================
+constexpr int kModeFlags = RTM_MODE_HOST_TRIG | RTM_MODE_COUNT_TESTS;  // flags OR-ed into rtm_options.mode
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
 const char* last_error() { return g_last_error.c_str(); }
@@ -325,16 +326,24 @@ static bool make_grid(const double* g, size_t n, GridBuild& out, double* pads_ou
     if (n < kGridMinSpheres || n >= (1u << 29) || !(lambda > 0.0)) return false;
     std::vector<double> R(n), pad(n);
     std::vector<char> is_big(n, 0);
+    std::vector<char> is_plane(n, 0);  // a png::PlaneObject's geometry row is (position, negative "r*r"): tested by every ray
     for (size_t i = 0; i < n; ++i) {
         const double* r = g + i * 4;
-        if (!(std::isfinite(r[0]) && std::isfinite(r[1]) && std::isfinite(r[2]) && std::isfinite(r[3]) && r[3] >= 0.0)) return false;
+        if (!(std::isfinite(r[0]) && std::isfinite(r[1]) && std::isfinite(r[2]) && std::isfinite(r[3]))) return false;
+        if (r[3] < 0.0) {
+            is_plane[i] = is_big[i] = 1;
+            R[i] = 0.0;
+            continue;
+        }
         unsigned long long wbits;
         std::memcpy(&wbits, &r[3], sizeof wbits);
         if (wbits & 0x1FFFFFFFull) return false;  // (never: r*r is a float widened to double — the records keep the index there)
         R[i] = std::sqrt(r[3]);
     }
     double lo[3], hi[3], h = 0.0, t_ok = 0.0;
-    size_t n_small = n;
+    size_t n_small = 0;
+    for (size_t i = 0; i < n; ++i) n_small += !is_plane[i];
+    if (n_small < kGridMinSpheres) return false;
     for (int round = 0; round < 4; ++round) {
         // box of the small spheres (unpadded), cell edge from its volume, pads from its diagonal
         for (int k = 0; k < 3; ++k) {
@@ -365,7 +374,7 @@ static bool make_grid(const double* g, size_t n, GridBuild& out, double* pads_ou
             // (rtm_path.h: a hit at parameter t lies sqrt(r^2 + t^2 (d.d - 1)) from the centre)
             pad[i] = 0.05 * h + (std::sqrt(R[i] * R[i] + kGridDdTol * t_ok * t_ok) - R[i]) + 1e-6 * t_ok;
             const double side = 2.0 * (R[i] + pad[i]) / h + 1.0;
-            const char b = !(side * side * side <= (double)kGridBigCells);
+            const char b = is_plane[i] || !(side * side * side <= (double)kGridBigCells);
             changed += b != is_big[i];
             is_big[i] = b;
             n_small += !b;
@@ -498,18 +507,32 @@ int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads
 
 // Build + upload; a scene that gets no grid keeps sc.grid empty (not an error).  `hg`: the host copy of the geometry rows.
 // `hm`: the material rows (kd in column 6), or null.
-static int build_scene_grid(rtm_scene& sc, const double* hg, const double* hm, size_t n, int device) {
+static int build_scene_grid(rtm_scene& sc, const double* hg, const double* hm, size_t n, int device,
+                            const double* plane_rows = nullptr) {
     GridBuild B;
-    if (sc.has_planes || !make_grid(hg, n, B)) return RTM_OK;
+    if (!make_grid(hg, n, B)) return RTM_OK;
     // A diffuse sphere that ENCLOSES the gridded ones from farther away than the pads reach (an environment sphere) sends
     // its bounces back from origins the walk cannot serve: each of them would take the exhaustive loop inside the grid
     // kernel, one lane at a time.  Such a scene keeps its grid for variant 17 by name; variant 0 leaves it alone (grid_for).
     sc.grid_far_bounces = false;
     const double reach = std::sqrt(B.hdr.reach2);
     for (int i : B.big) {
+        const bool diffuse = !hm || hm[(size_t)i * 8 + 6] > 0.0;
+        if (hg[(size_t)i * 4 + 3] < 0.0) {  // a plane: any of its square's corners beyond the reach?
+            if (!plane_rows) return RTM_OK;  // (no rows to judge it by: no grid)
+            const double* pl = plane_rows + (size_t)i * 16;
+            for (int c = 0; c < 4 && diffuse; ++c) {
+                double d2 = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    const double p = pl[k] + ((c & 1) ? pl[6 + k] : -pl[6 + k]) + ((c & 2) ? pl[9 + k] : -pl[9 + k]);
+                    d2 += (p - B.hdr.cb[k]) * (p - B.hdr.cb[k]);
+                }
+                if (!(std::sqrt(d2) <= reach)) sc.grid_far_bounces = true;
+            }
+            continue;
+        }
         double d2 = 0.0;
         for (int k = 0; k < 3; ++k) d2 += (hg[(size_t)i * 4 + k] - B.hdr.cb[k]) * (hg[(size_t)i * 4 + k] - B.hdr.cb[k]);
-        const bool diffuse = !hm || hm[(size_t)i * 8 + 6] > 0.0;
         if (diffuse && std::sqrt(hg[(size_t)i * 4 + 3]) - std::sqrt(d2) > reach) sc.grid_far_bounces = true;
     }
     const size_t off_cs = (sizeof(GridHeader) + 255) & ~(size_t)255;
@@ -658,6 +681,10 @@ int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene
         if ((rc = sc->plane.alloc_pooled(rows.size() * sizeof(double), device)) != RTM_OK) return rc;
         RTM_HIP_CHECK(hipMemcpy(sc->plane.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
         sc->has_planes = true;
+        // the grid of a scene with planes: over its spheres, the planes among the objects every ray tests (build_scene_grid)
+        std::vector<double> hm((n + 1) * 8);
+        RTM_HIP_CHECK(hipMemcpy(hm.data(), sc->mat.p, hm.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if ((rc = build_scene_grid(*sc, hg.data(), hm.data(), n, device, rows.data())) != RTM_OK) return rc;
     }
     *out = sc.release();
     return RTM_OK;
@@ -904,7 +931,7 @@ static int validate(const rtm_settings* st, const rtm_sphere* sp, size_t n, cons
         set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
-    if ((opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_LITERAL && (opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_REPAIRED) {
+    if ((opt->mode & ~kModeFlags) != RTM_MODE_LITERAL && (opt->mode & ~kModeFlags) != RTM_MODE_REPAIRED) {
         set_last_error("unknown mode");
         return RTM_ERR_INVALID_ARGUMENT;
     }
@@ -945,11 +972,14 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                       ("LABELLED-fp32-fast (single precision, hardware sqrt/rsq/sin/cos, fused multiply-adds, "
                                        "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)"),
                                       ("fast-math-uniform-grid (large scenes held by an rtm_scene: the reference loop's nearest hit "
-                                       "through a uniform grid over the spheres, same image bit for bit)")};
+                                       "through a uniform grid over the spheres, same image bit for bit)"),
+                                      ("LABELLED-fp64-tolerance (the default kernel compiled with FMA contraction and one-ulp division / "
+                                       "square root, float islands, RNG, thresholds and addition order kept: within north_star's 1e-4 per "
+                                       "pixel, NOT bit-exact by construction; reported with its differing-pixel count)")};
 #undef RTM_RETIRED
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3, kVariantStamped = 7,
               kVariantSplit = 9, kVariantWavefrontRejectF32 = 12, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15,
-              kVariantFp32 = 16, kVariantGrid = 17;
+              kVariantFp32 = 16, kVariantGrid = 17, kVariantTol = 18;
 static bool variant_retired(int v) { return v == 4 || v == 5 || v == 6 || v == 8 || v == 10 || v == 11 || v == 13; }
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
@@ -976,7 +1006,7 @@ static void fill_render_params(RenderParams& P, const rtm_settings* st, const rt
     P.band_count = opt->band_count > 1 ? opt->band_count : 1;
     P.band_index = opt->band_count > 1 ? opt->band_index : 0;
     P.tiles_x = (st->width + 7) / 8;
-    P.mode = opt->mode & ~RTM_MODE_HOST_TRIG;
+    P.mode = opt->mode & ~kModeFlags;
     P.max_bounces = opt->max_bounces;
     P.total_samples = (unsigned)st->super_samples * st->super_samples * st->samples;
     P.rate = (float)(1.0 / (1 + st->super_samples));
@@ -1178,9 +1208,9 @@ struct StreamCtx {
     bool ready = false;
     int init() {
         if (ready) return RTM_OK;
-        RTM_HIP_CHECK(hipMalloc((void**)&sticky, 8 * sizeof(unsigned long long)));
-        counters = sticky + 4;
-        RTM_HIP_CHECK(hipMemset(sticky, 0, 8 * sizeof(unsigned long long)));
+        RTM_HIP_CHECK(hipMalloc((void**)&sticky, 16 * sizeof(unsigned long long)));
+        counters = sticky + 8;  // casts, bounces, draws, overflow flag, object tests (RTM_MODE_COUNT_TESTS)
+        RTM_HIP_CHECK(hipMemset(sticky, 0, 16 * sizeof(unsigned long long)));
         RTM_HIP_CHECK(hipHostMalloc((void**)&flag_host, 64, hipHostMallocDefault));
         std::memset(flag_host, 0, 64);
         wf_count_host = reinterpret_cast<unsigned*>(flag_host + 2);
@@ -1284,6 +1314,71 @@ static int cached_scene(const rtm_sphere* sp, size_t n, int device, std::shared_
     return RTM_OK;
 }
 
+// Content hash of a device array, order-independent over (index, word) pairs: sum of smfin64(word + (index + 1) * odd).
+__global__ __launch_bounds__(256) void hash_words_kernel(const unsigned long long* __restrict__ w, size_t n_words,
+                                                         unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256)
+        acc += smfin64(w[i] + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+namespace {
+struct DeviceArrayCache {
+    struct Entry {
+        int device;
+        size_t n;
+        unsigned long long hash;
+        std::shared_ptr<rtm_scene> scene;
+    };
+    std::mutex mu;
+    std::vector<Entry> entries;  // most recently used last
+};
+DeviceArrayCache& device_array_cache() {  // (never destroyed: its scenes' deleter calls HIP)
+    static DeviceArrayCache* c = new DeviceArrayCache;
+    return *c;
+}
+}  // namespace
+// The cached scene object for a DEVICE sphere array (render_device).  Waits for `stream` once (the hash).
+static int cached_device_scene(const rtm_sphere* sp_dev, size_t n, int device, hipStream_t stream, std::shared_ptr<rtm_scene>* out) {
+    unsigned long long h = 0ull;
+    {
+        StreamCtx& ctx = *get_ctx(device, stream);
+        std::lock_guard<std::mutex> lock(ctx.mu);
+        int rc = ctx.init();
+        if (rc != RTM_OK) return rc;
+        unsigned long long* slot = ctx.sticky + 7;                     // device word of the context nobody else uses
+        volatile unsigned long long* host = ctx.flag_host + 4;         // pinned
+        static_assert(sizeof(rtm_sphere) % 8 == 0, "the array is hashed in 8-byte words");
+        const size_t words = n * sizeof(rtm_sphere) / 8;
+        RTM_HIP_CHECK(hipMemsetAsync(slot, 0, 8, stream));
+        const unsigned blocks = (unsigned)std::min<size_t>(1024, (words + 255) / 256);
+        hash_words_kernel<<<blocks, 256, 0, stream>>>(reinterpret_cast<const unsigned long long*>(sp_dev), words, slot);
+        RTM_HIP_CHECK(hipGetLastError());
+        RTM_HIP_CHECK(hipMemcpyAsync((void*)host, slot, 8, hipMemcpyDeviceToHost, stream));
+        RTM_HIP_CHECK(hipStreamSynchronize(stream));
+        h = *host;
+    }
+    DeviceArrayCache& cache = device_array_cache();
+    std::lock_guard<std::mutex> lock(cache.mu);
+    auto& e = cache.entries;
+    for (size_t i = 0; i < e.size(); ++i)
+        if (e[i].device == device && e[i].n == n && e[i].hash == h) {
+            if (i + 1 != e.size()) std::rotate(e.begin() + (long)i, e.begin() + (long)i + 1, e.end());
+            *out = e.back().scene;
+            return RTM_OK;
+        }
+    std::vector<rtm_sphere> host_copy(n);
+    RTM_HIP_CHECK(hipMemcpy(host_copy.data(), sp_dev, n * sizeof(rtm_sphere), hipMemcpyDeviceToHost));
+    std::shared_ptr<rtm_scene> sc(new rtm_scene, [](rtm_scene* p) { (void)scene_destroy(p); });
+    const int rc = scene_build_host(*sc, host_copy.data(), n, device);
+    if (rc != RTM_OK) return rc;
+    if (e.size() >= kSceneCacheEntries) e.erase(e.begin());  // (the deleter parks it if a render from it is still queued)
+    e.push_back(DeviceArrayCache::Entry{device, n, h, sc});
+    *out = sc;
+    return RTM_OK;
+}
+
 int release_scratch(int device) {
     std::unique_lock<std::shared_mutex> gate(g_gate);  // no render is mid-call from here on
     {
@@ -1308,6 +1403,14 @@ int release_scratch(int device) {
             } else {
                 ++it;
             }
+        }
+    }
+    {
+        DeviceArrayCache& cache = device_array_cache();
+        std::lock_guard<std::mutex> lock(cache.mu);
+        for (auto it = cache.entries.begin(); it != cache.entries.end();) {
+            if (device < 0 || it->device == device) it = cache.entries.erase(it);
+            else ++it;
         }
     }
     std::lock_guard<std::mutex> lock(g_ctx_mu);
@@ -1417,22 +1520,14 @@ static SplitPlan choose_split(unsigned n_tiles, unsigned total_samples, int devi
 //    the count of batch b-1 only after batch b has been queued behind it — the GPU never waits for the host, but the
 //    call returns only when the count has been seen at zero.
 constexpr unsigned long long kWfAsyncTrips = 16384;
-static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, bool may_block) {
+struct RenderPlan;
+static int run_wavefront_impl(const RenderParams& P, int rows, StreamCtx& ctx, bool may_block, int levels, size_t bytes) {
     hipStream_t stream = ctx.stream;
     WfState S;
     std::memset(&S, 0, sizeof S);
     S.npix = (unsigned)rows * (unsigned)P.W;
-    // record levels per pixel: the cap when there is one, else as many as 2 GiB of HBM buy
-    // (64..1024); a deeper path raises the overflow flag like in the other variants
-    if (P.max_bounces >= 0 && P.max_bounces <= 1024) {
-        S.levels = P.max_bounces > 0 ? P.max_bounces : 1;
-    } else {
-        const size_t budget = ((size_t)2 << 30) / (4 * (size_t)S.npix);
-        S.levels = (int)(budget < 64 ? 64 : (budget > 1024 ? 1024 : budget));
-    }
+    S.levels = levels;  // (plan_render: the cap when there is one, else as many as 2 GiB of HBM buy)
     const size_t N = S.npix;
-    const size_t part_bytes = (size_t)(kWfMaxParts - 1) * kWfPartSlots * 12 + 64;
-    const size_t bytes = N * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)S.levels * 4 + 2 * 4) + 256 + part_bytes;
     unsigned char* ws = nullptr;
     int rc = scratch_acquire(ctx, kScratchWavefront, bytes, (void**)&ws);
     if (rc != RTM_OK) return rc;
@@ -1561,8 +1656,10 @@ static int take_stream_status(StreamCtx& ctx, bool wait) {
 }
 
 // rtm_stream_release: the (device, stream) context goes — after the stream's queued work, which may still use its buffers.
+// The gate is taken EXCLUSIVELY, like release_scratch: a render on the same pair that has looked its context up
+// (render_view: get_ctx) and is about to lock it must not find the mutex and the scratch pointers freed under it.
 int stream_release(int device, void* stream_v) {
-    std::shared_lock<std::shared_mutex> gate(g_gate);
+    std::unique_lock<std::shared_mutex> gate(g_gate);
     DeviceGuard guard;
     RTM_HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<StreamCtx> ctx;
@@ -1598,85 +1695,79 @@ int stream_status(int device, void* stream_v) {
 // a 1080p frame at 256 spp): beyond kGridTermBudget — or what the device will give — the frame is rendered in several
 // launches of as many tiles as fit, one behind the other on the stream, each followed by its finalize.
 constexpr size_t kGridTermBudget = (size_t)16 << 30;
-static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx) {
-    static const bool xcd_off = [] {
-        const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
-        return e && e[0] == '0';
-    }();
+static void launch_grid_kernel(const RenderParams& P, unsigned base, unsigned cnt, size_t lds, bool deep, bool planes, bool count,
+                               hipStream_t stream) {
+    (void)planes;  // (a plane is found at run time, wave-uniformly, among the objects every ray tests: no instantiation of its own)
+    if (count) {
+        if (deep) render_grid_kernel<uint32_t, 32, true><<<cnt, 64, lds, stream>>>(P, base);
+        else render_grid_kernel<uint32_t, 16, true><<<cnt, 64, lds, stream>>>(P, base);
+    } else {
+        if (deep) render_grid_kernel<uint32_t, 32, false><<<cnt, 64, lds, stream>>>(P, base);
+        else render_grid_kernel<uint32_t, 16, false><<<cnt, 64, lds, stream>>>(P, base);
+    }
+}
+
+// ---- planning a render: everything that is decided before anything is allocated or launched ---------------------------
+// The resolved kernel variant, the sample split and stealing plans, and the bytes of every per-(device, stream) work buffer
+// the call will ask for (0 = none).  render_view acquires exactly these (and falls back where the plan says a buffer is
+// optional); rtm_scratch_bytes reports them without touching the device's memory.
+struct RenderPlan {
+    int variant = 0;          // resolved
+    bool tol = false;         // the labelled tolerance row (launched from rtm_kernels_tol.hip, planned like variant 2)
+    bool force_split = false;
+    bool packl = false;
+    bool count_tests = false; // RTM_MODE_COUNT_TESTS
+    unsigned grid = 0;        // tiles of the launch
+    int rows = 0;
+    size_t bytes[kScratchRoles] = {0, 0, 0, 0};
+    bool optional[kScratchRoles] = {false, false, false, false};  // without room the launch runs without the feature
+    // steal plan
+    unsigned steal_rows = 0, steal_depth = 0;
+    bool steal = false;
+    // wavefront plan
+    int wf_levels = 0;
+    // grid plan
+    size_t grid_chunk_tiles = 0;
+};
+
+static size_t grid_term_budget() {
     static const size_t budget = [] {
         const char* e = std::getenv("RTM_DEBUG_GRID_BUDGET_MB");  // test knob: the term buffer's budget in MiB (several launches per frame)
         return e ? (size_t)std::strtoull(e, nullptr, 10) << 20 : kGridTermBudget;
     }();
-    const size_t per_tile = grid_tile_term_bytes(P.total_samples);
-    size_t chunk = std::min<size_t>(tiles, std::max<size_t>(1, budget / per_tile));
-    void* ws = nullptr;
-    for (;;) {
-        if (scratch_acquire(ctx, kScratchTerms, chunk * per_tile, &ws) == RTM_OK) break;
-        (void)hipGetLastError();
-        if (chunk <= 64) {
-            set_last_error("no device memory for the grid kernel's term buffer");
-            return RTM_ERR_HIP;
-        }
-        chunk = (chunk + 1) / 2;
-    }
-    P.contrib = static_cast<unsigned char*>(ws);
-    const bool deep = needs_pool(P);
-    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
-                       GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
-    for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
-        const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);
-        P.xcd_on = xcd_off ? 0u : 1u;
-        P.xcd_q = cnt / 8u;
-        P.xcd_rem = cnt % 8u;
-        if (deep) render_grid_kernel<uint32_t, 32><<<cnt, 64, lds, ctx.stream>>>(P, base);
-        else render_grid_kernel<uint32_t, 16><<<cnt, 64, lds, ctx.stream>>>(P, base);
-        grid_finalize_kernel<<<cnt, 64, 0, ctx.stream>>>(P, base);
-    }
-    RTM_HIP_CHECK(hipGetLastError());
-    return RTM_OK;
+    return budget;
+}
+static size_t wavefront_bytes(size_t npix, int levels) {
+    const size_t part_bytes = (size_t)(kWfMaxParts - 1) * kWfPartSlots * 12 + 64;
+    return npix * (3 * 8 * 4 + 8 + 4 + 4 * 5 + (size_t)levels * 4 + 2 * 4) + 256 + part_bytes;
+}
+static int wavefront_levels(const RenderParams& P, size_t npix) {
+    // record levels per pixel: the cap when there is one, else as many as 2 GiB of HBM buy (64..1024); a deeper path
+    // raises the overflow flag like in the other variants
+    if (P.max_bounces >= 0 && P.max_bounces <= 1024) return P.max_bounces > 0 ? P.max_bounces : 1;
+    const size_t budget = ((size_t)2 << 30) / (4 * (npix ? npix : 1));
+    return (int)(budget < 64 ? 64 : (budget > 1024 ? 1024 : budget));
 }
 
-static int render_view(const rtm_settings* st, const SceneView& view, size_t n, const rtm_options* opt,
-                       double* out64, float* out32, uint8_t* out8, hipStream_t stream, rtm_stats* stats) {
-    RTM_HIP_CHECK(hipSetDevice(opt->device));
-    const int rows = output_rows(opt);
-    if (stats) std::memset(stats, 0, sizeof *stats);
-    StreamCtx& ctx = *get_ctx(opt->device, stream);
-    std::lock_guard<std::mutex> lock(ctx.mu);
-    int rc = ctx.init();
-    if (rc != RTM_OK) return rc;
-    rc = take_stream_status(ctx, false);  // an overflow of an earlier render that has reached the host
-    if (rc != RTM_OK) return rc;
-    if (rows == 0) return RTM_OK;
-
-    RenderParams P;
+// Fills P (camera, sizes, split fields) and the plan.  `view`: what the scene offers (planes, grid).
+static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, const rtm_options* opt, RenderParams& P,
+                       RenderPlan& plan) {
     std::memset(&P, 0, sizeof P);
     fill_render_params(P, st, opt);
     P.scene = view;
-    if (opt->mode & RTM_MODE_HOST_TRIG) {
-        const uint32_t* fix = nullptr;
-        rc = ensure_trig_fix(opt->device, &fix);
-        if (rc != RTM_OK) return rc;
-        P.scene.trig_fix = fix;
-    }
-    P.out64 = out64;
-    P.out32 = out32;
-    P.out8 = out8;
-    P.counters = stats ? ctx.counters : ctx.sticky;
-    if (stats) RTM_HIP_CHECK(hipMemsetAsync(ctx.counters, 0, 4 * sizeof(unsigned long long), stream));
-    unsigned char* pool = nullptr;
-    const unsigned tiles_y = (unsigned)((rows + 7) / 8);
+    plan.rows = output_rows(opt);
+    plan.count_tests = (opt->mode & RTM_MODE_COUNT_TESTS) != 0;
+    const unsigned tiles_y = (unsigned)((plan.rows + 7) / 8);
     const unsigned grid = (unsigned)P.tiles_x * tiles_y;
-    // sample split (default kernel only): per-sample terms of waves 1.. in the stream's term buffer
+    plan.grid = grid;
     int variant = opt->variant;
-    double* split_ws = nullptr;
     P.n_tiles = grid;
     P.split = 1;
     P.split_len = P.split_head = P.total_samples;
     // auto (profiles/r1/variant_thresholds.txt): LDS tables up to 24 spheres (8.5 KB of LDS per wave keeps
     // 16 waves per CU); global-memory tables up to 511 (the tables no longer cost occupancy); from 512
     // spheres the wavefront pipeline with its rejection test wins over the monolithic kernel
-    const bool force_split = variant == kVariantSplit;
+    plan.force_split = variant == kVariantSplit;
     if (variant < 0 || variant >= num_variants() || variant_retired(variant)) {
         set_last_error(variant >= 0 && variant < num_variants() ? std::string("variant ") + std::to_string(variant) + ": " + kVariantNames[variant]
                                                                 : std::string("no such variant"));
@@ -1688,18 +1779,32 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                   n < 256 ? kVariantGlobalDefer :
                   n < (size_t)kAutoWavefrontSpheres ? kVariantFastGlobal : kVariantWavefrontRejectF32;
     if (variant == kVariantGrid && view.grid == nullptr) {
-        set_last_error("variant 17 (uniform grid) serves all-sphere scenes of 64 gridded spheres or more held by an rtm_scene "
-                       "(rtm_scene_create*, rtm_render_rows*); this scene has no grid");
+        set_last_error("variant 17 (uniform grid) serves scenes of 64 gridded spheres or more held by an rtm_scene "
+                       "(rtm_scene_create*, rtm_render_rows*) or made per call from a device array; this scene has no grid");
         return RTM_ERR_UNSUPPORTED;
     }
     else if (variant == kVariantSplit)
         variant = kVariantFastLds;
-    if (view.plane != nullptr) {
+    // variant 18, the labelled tolerance row (rtm_kernels_tol.hip): planned exactly like the default kernel of small scenes —
+    // sample split of the last tiles, in-wave sample stealing — and launched from the other translation unit
+    const bool tol = variant == kVariantTol;
+    plan.tol = tol;
+    if (tol) {
+        if (!(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && view.plane == nullptr && P.max_bounces >= 0 && P.max_bounces <= 8 &&
+              P.total_samples < 65536u)) {
+            set_last_error("variant 18 (fp64 tolerance row) serves all-sphere scenes of 1..24 spheres with 0 <= max_bounces <= 8 and "
+                           "fewer than 65 536 samples per pixel");
+            return RTM_ERR_UNSUPPORTED;
+        }
+        variant = kVariantFastLds;
+    }
+    if (view.plane != nullptr && variant != kVariantGrid) {
         // png::PlaneObject in the scene: the chunked LDS-table kernels serve it up to 255 objects (variants 0, 2, 9), the
+        // grid kernel scenes that have a grid (planes are tested by every ray, next to the spheres that span the scene), the
         // per-object loop with the compiler's math (variant 1) any size; the other kernels know spheres only
         if (opt->variant != kVariantAuto && opt->variant != kVariantRef && opt->variant != kVariantFastLds &&
             opt->variant != kVariantSplit) {
-            set_last_error("scenes that hold planes are rendered by variants 0 (auto), 1 (per-object loop), 2 and 9");
+            set_last_error("scenes that hold planes are rendered by variants 0 (auto), 1 (per-object loop), 2, 9 and 17");
             return RTM_ERR_UNSUPPORTED;
         }
         if (opt->variant == kVariantRef || n >= 256)
@@ -1720,29 +1825,20 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         return RTM_ERR_UNSUPPORTED;
     }
     // the sample split rides on the packed-record kernels (explicit variant 2 never splits)
-    if (n < 256 && (opt->variant == kVariantAuto || force_split) &&
+    if (n < 256 && (opt->variant == kVariantAuto || plan.force_split || tol) &&
         (variant == kVariantFastLds || variant == kVariantGlobalDefer)) {
-        const SplitPlan plan = choose_split(grid, P.total_samples, opt->device, force_split);
-        P.split = plan.g;
+        const SplitPlan sp = choose_split(grid, P.total_samples, opt->device, plan.force_split);
+        P.split = sp.g;
         if (P.split > 1) {
-            P.n_tiles = plan.tiles;
-            P.split_first = grid - plan.tiles;
+            P.n_tiles = sp.tiles;
+            P.split_first = grid - sp.tiles;
             P.split_len = P.total_samples / P.split;
-            P.split_head = plan.head;
+            P.split_head = sp.head;
             P.split = 1u + (P.total_samples - P.split_head) / P.split_len;
             const size_t part = (size_t)P.n_tiles * 192 * sizeof(double);
             const size_t terms = (size_t)P.n_tiles * (P.total_samples - P.split_head) * kTermRowBytes;  // a row per (tile, sample)
-            rc = scratch_acquire(ctx, kScratchTerms, part + terms, (void**)&split_ws);
-            if (rc == RTM_OK) {
-                P.partial = split_ws;
-                P.contrib = reinterpret_cast<unsigned char*>(split_ws) + part;
-            } else {  // no room for the terms: the launch runs unsplit (same image, a longer tail) instead of failing
-                (void)hipGetLastError();
-                P.split = 1;
-                P.n_tiles = grid;
-                P.split_first = 0;
-                P.split_len = P.split_head = P.total_samples;
-            }
+            plan.bytes[kScratchTerms] = part + terms;
+            plan.optional[kScratchTerms] = true;  // no room for the terms: the launch runs unsplit (same image, a longer tail)
         }
     }
     // In-wave sample stealing for the whole tiles of the packed-record LDS-table kernel (rtm_render_kernel.h, STEAL): a
@@ -1753,33 +1849,180 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         const char* e = std::getenv("RTM_DEBUG_STEAL");  // tuning knob: 0 = no sample stealing
         return e && e[0] == '0';
     }();
+    const unsigned n_whole = P.split > 1 ? P.split_first : grid;
     if (!steal_off && variant == kVariantFastLds && view.plane == nullptr && n >= 1 && n < 256 /* packed records: PACK8 */ &&
         P.max_bounces >= 0 && P.max_bounces <= 8 && P.total_samples >= 16 && P.total_samples < 65536u && st->samples < 65536 &&
-        opt->variant != kVariantFastLds /* explicit variant 2 stays the plain kernel: the A/B twin */) {
-        const unsigned n_whole = P.split > 1 ? P.split_first : grid;
+        opt->variant != kVariantFastLds /* explicit variant 2 stays the plain kernel: the A/B twin */ &&
+        !(tol && std::getenv("RTM_DEBUG_TOL_NOSTEAL") != nullptr) /* test knob: the tolerance row's stealing-free path */ &&
+        n_whole != 0) {
         unsigned rows = 2u * (unsigned)std::ceil(std::sqrt((double)P.total_samples)) + 4u;
         rows = rows < 8u ? 8u : (rows > 68u ? 68u : rows);
         unsigned depth = P.total_samples / 2u;
         depth = depth > 256u ? 256u : depth;
+        plan.steal = true;
+        plan.steal_rows = rows;
+        plan.steal_depth = depth;
+        plan.bytes[kScratchSteal] = (size_t)n_whole * steal_tile_bytes(rows);
+        plan.optional[kScratchSteal] = !tol;
+    } else if (tol) {
+        // the tolerance row has the STEAL instantiation only: frames the stealing declines (fewer than 16 samples per pixel)
+        // run it with no row to steal into — every lane traces its own samples, the tile's block carries the accumulators
+        // to steal_finalize_kernel
+        plan.bytes[kScratchSteal] = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(0);
+    }
+    if (tol) plan.bytes[kScratchSteal] += (size_t)grid * 64 * sizeof(unsigned long long);  // + the primary-ray masks (prim_mask_kernel)
+    // deep-path record pool.  Kernels with an LDS record stack take a slot only for the
+    // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
+    // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
+    plan.packl = n < 256 && !(P.max_bounces >= 0 && P.max_bounces <= 8) &&
+                 (variant == kVariantFastLds || variant == kVariantGlobalDefer);
+    if (needs_pool(P) && variant != kVariantWavefrontRejectF32 && variant != kVariantFp32) {
+        // the record type of the kernel that will run: the grid kernel is instantiated for 4-byte records whatever n
+        const size_t rec_bytes = (variant == kVariantGrid || n > 256) ? 4 : 1;
+        P.pool_slots = plan.packl ? (P.split_first + P.n_tiles * P.split) * 128u : 65536u;  // two per lane
+        plan.bytes[kScratchPool] = (size_t)P.pool_slots * kPoolLevels * rec_bytes + 64;
+    }
+    if (variant == kVariantWavefrontRejectF32) {
+        const size_t npix = (size_t)plan.rows * (size_t)P.W;
+        plan.wf_levels = wavefront_levels(P, npix);
+        plan.bytes[kScratchWavefront] = wavefront_bytes(npix, plan.wf_levels);
+    }
+    if (variant == kVariantGrid) {
+        const size_t per_tile = grid_tile_term_bytes(P.total_samples);
+        plan.grid_chunk_tiles = std::min<size_t>(grid, std::max<size_t>(1, grid_term_budget() / per_tile));
+        plan.bytes[kScratchTerms] = plan.grid_chunk_tiles * per_tile;
+        plan.optional[kScratchTerms] = true;  // what the device will not give is made up for by more launches of fewer tiles
+    }
+    plan.variant = variant;
+    return RTM_OK;
+}
+
+static int run_wavefront(const RenderParams& P, int rows, StreamCtx& ctx, bool may_block, const RenderPlan& plan) {
+    return run_wavefront_impl(P, rows, ctx, may_block, plan.wf_levels, plan.bytes[kScratchWavefront]);
+}
+
+static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const RenderPlan& plan) {
+    static const bool xcd_off = [] {
+        const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
+        return e && e[0] == '0';
+    }();
+    const size_t per_tile = grid_tile_term_bytes(P.total_samples);
+    size_t chunk = plan.grid_chunk_tiles;
+    void* ws = nullptr;
+    // What the device can give, asked once (a failed multi-GB hipMalloc after the old buffer has been freed costs a stream
+    // synchronisation per attempt): a buffer that has to grow is sized to what is free, never below 64 tiles.
+    if (ctx.scratch[kScratchTerms].bytes < chunk * per_tile) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t usable = free_b + ctx.scratch[kScratchTerms].bytes;  // the old buffer goes before the new one comes
+            const size_t keep = (size_t)512 << 20;
+            if (usable > keep && (usable - keep) / per_tile < chunk) chunk = std::max<size_t>(std::min<size_t>(64, chunk), (usable - keep) / per_tile);
+        }
+        (void)hipGetLastError();
+    }
+    for (;;) {
+        if (scratch_acquire(ctx, kScratchTerms, chunk * per_tile, &ws) == RTM_OK) break;
+        (void)hipGetLastError();
+        if (chunk <= 64) {
+            set_last_error("no device memory for the grid kernel's term buffer");
+            return RTM_ERR_HIP;
+        }
+        chunk = (chunk + 1) / 2;
+    }
+    P.contrib = static_cast<unsigned char*>(ws);
+    const bool deep = needs_pool(P);
+    const bool planes = P.scene.plane != nullptr;
+    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
+                       GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
+    for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
+        const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);
+        P.xcd_on = xcd_off ? 0u : 1u;
+        P.xcd_q = cnt / 8u;
+        P.xcd_rem = cnt % 8u;
+        launch_grid_kernel(P, base, cnt, lds, deep, planes, plan.count_tests, ctx.stream);
+        grid_finalize_kernel<<<cnt, 64, 0, ctx.stream>>>(P, base);
+    }
+    RTM_HIP_CHECK(hipGetLastError());
+    return RTM_OK;
+}
+
+static int render_view(const rtm_settings* st, const SceneView& view, size_t n, const rtm_options* opt,
+                       double* out64, float* out32, uint8_t* out8, hipStream_t stream, rtm_stats* stats) {
+    RTM_HIP_CHECK(hipSetDevice(opt->device));
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    StreamCtx& ctx = *get_ctx(opt->device, stream);
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    int rc = ctx.init();
+    if (rc != RTM_OK) return rc;
+    rc = take_stream_status(ctx, false);  // an overflow of an earlier render that has reached the host
+    if (rc != RTM_OK) return rc;
+    if (output_rows(opt) == 0) return RTM_OK;
+
+    RenderParams P;
+    RenderPlan plan;
+    rc = plan_render(st, view, n, opt, P, plan);
+    if (rc != RTM_OK) return rc;
+    const int rows = plan.rows;
+    const unsigned grid = plan.grid;
+    const int variant = plan.variant;
+    const bool tol = plan.tol;
+    if (opt->mode & RTM_MODE_HOST_TRIG) {
+        const uint32_t* fix = nullptr;
+        rc = ensure_trig_fix(opt->device, &fix);
+        if (rc != RTM_OK) return rc;
+        P.scene.trig_fix = fix;
+    }
+    P.out64 = out64;
+    P.out32 = out32;
+    P.out8 = out8;
+    P.counters = stats ? ctx.counters : ctx.sticky;
+    if (stats) RTM_HIP_CHECK(hipMemsetAsync(ctx.counters, 0, 5 * sizeof(unsigned long long), stream));
+    // the sample split's terms (the default kernels only; the grid kernel sizes its own buffer in run_grid)
+    if (P.split > 1) {
+        double* split_ws = nullptr;
+        rc = scratch_acquire(ctx, kScratchTerms, plan.bytes[kScratchTerms], (void**)&split_ws);
+        if (rc == RTM_OK) {
+            P.partial = split_ws;
+            P.contrib = reinterpret_cast<unsigned char*>(split_ws) + (size_t)P.n_tiles * 192 * sizeof(double);
+        } else {  // no room for the terms: the launch runs unsplit (same image, a longer tail) instead of failing
+            (void)hipGetLastError();
+            P.split = 1;
+            P.n_tiles = grid;
+            P.split_first = 0;
+            P.split_len = P.split_head = P.total_samples;
+        }
+    }
+    if (plan.bytes[kScratchSteal] != 0) {
+        const unsigned n_whole = P.split > 1 ? P.split_first : grid;  // (an unsplit fallback has more whole tiles than planned)
+        unsigned srows = plan.steal ? plan.steal_rows : 0u;
         void* ws = nullptr;
-        if (n_whole != 0 && scratch_acquire(ctx, kScratchSteal, (size_t)n_whole * steal_tile_bytes(rows), &ws) == RTM_OK) {
+        const size_t mask_bytes = tol ? (size_t)grid * 64 * sizeof(unsigned long long) : 0;  // behind the tiles' blocks
+        size_t blocks = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(srows);
+        rc = (n_whole || tol) ? scratch_acquire(ctx, kScratchSteal, blocks + mask_bytes, &ws) : RTM_ERR_HIP;
+        if (rc != RTM_OK && tol) {  // the tolerance row cannot run without its blocks: the smallest form, or fail
+            (void)hipGetLastError();
+            srows = 0;
+            blocks = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(0);
+            rc = scratch_acquire(ctx, kScratchSteal, blocks + mask_bytes, &ws);
+            if (rc != RTM_OK) return rc;
+        }
+        if (rc == RTM_OK) {
+            if (tol) P.prim_masks = reinterpret_cast<const unsigned long long*>(static_cast<unsigned char*>(ws) + blocks);
             P.steal_ws = static_cast<unsigned char*>(ws);
-            P.steal_rows = rows;
-            P.steal_depth = depth;
-            P.magic_S = (unsigned)(0x100000000ull / (unsigned long long)st->samples) + 1u;
-            P.magic_SS = (unsigned)(0x100000000ull / (unsigned long long)st->super_samples) + 1u;
+            P.steal_rows = srows;
+            P.steal_depth = srows ? plan.steal_depth : 0u;
+            if (srows || tol) {  // (the tolerance row divides a sample index by S in its tail loop whether it steals or not)
+                P.magic_S = (unsigned)(0x100000000ull / (unsigned long long)st->samples) + 1u;
+                P.magic_SS = (unsigned)(0x100000000ull / (unsigned long long)st->super_samples) + 1u;
+            }
         } else {
             (void)hipGetLastError();
         }
     }
-    // deep-path record pool.  Kernels with an LDS record stack take a slot only for the
-    // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
-    // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
-    const bool packl = n < 256 && !(P.max_bounces >= 0 && P.max_bounces <= 8) &&
-                       (variant == kVariantFastLds || variant == kVariantGlobalDefer);
-    if (needs_pool(P)) {
-        const size_t rec_bytes = (n <= 256) ? 1 : 4;
-        P.pool_slots = packl ? (P.split_first + P.n_tiles * P.split) * 128u : 65536u;  // two per lane
+    if (plan.bytes[kScratchPool] != 0) {
+        unsigned char* pool = nullptr;
+        if (plan.packl) P.pool_slots = (P.split_first + P.n_tiles * P.split) * 128u;  // (after a possible unsplit fallback)
+        const size_t rec_bytes = (variant == kVariantGrid || n > 256) ? 4 : 1;
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
         rc = scratch_acquire(ctx, kScratchPool, pool_bytes + 64, (void**)&pool);
         if (rc != RTM_OK) return rc;
@@ -1803,10 +2046,13 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         RTM_HIP_CHECK(hipEventRecord(ev.a, stream));
     }
     if (variant == kVariantWavefrontRejectF32) {
-        rc = run_wavefront(P, rows, ctx, stats != nullptr);
+        rc = run_wavefront(P, rows, ctx, stats != nullptr, plan);
         if (rc != RTM_OK) return rc;
     } else if (variant == kVariantGrid) {
-        rc = run_grid(P, grid, ctx);
+        rc = run_grid(P, grid, ctx, plan);
+        if (rc != RTM_OK) return rc;
+    } else if (tol) {
+        rc = launch_tol(&P, sizeof P, grid, debug_lds_pad(), stream);
         if (rc != RTM_OK) return rc;
     } else {
         launch_render(variant, P, grid, stream);
@@ -1829,7 +2075,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         return RTM_OK;
     }
     RTM_HIP_CHECK(hipEventRecord(ev.b, stream));
-    unsigned long long c[4];
+    unsigned long long c[5];
     RTM_HIP_CHECK(hipMemcpyAsync(c, ctx.counters, sizeof c, hipMemcpyDeviceToHost, stream));
     RTM_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.f;
@@ -1839,8 +2085,11 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     stats->bounces = c[1];
     stats->draws = c[2];
     stats->kernel_ms = ms;
-    stats->variant = variant;
+    stats->variant = tol ? kVariantTol : variant;
     stats->split = (int32_t)P.split;
+    // Intersect calls (src/Renderer.cpp:66) the render made: every object for every cast in the exhaustive kernels; counted
+    // by the grid kernel when RTM_MODE_COUNT_TESTS asks for its counting instantiation (0: not counted)
+    stats->object_tests = variant == kVariantGrid ? (plan.count_tests ? c[4] : 0ull) : c[0] * (uint64_t)n;
     if (c[3]) {
         set_last_error(kOverflowText);
         return RTM_ERR_UNSUPPORTED;
@@ -1858,6 +2107,32 @@ static const void* grid_for(const rtm_scene* sc, const rtm_settings* st, const r
     double d2 = 0.0;
     for (int k = 0; k < 3; ++k) d2 += (st->camera.origin[k] - sc->grid_hdr.cb[k]) * (st->camera.origin[k] - sc->grid_hdr.cb[k]);
     return (d2 <= sc->grid_hdr.reach2) ? sc->grid.p : nullptr;  // (NaN: no)
+}
+
+// rtm_scratch_bytes: what a render with these arguments asks of the per-(device, stream) work buffers (plan_render), without
+// touching the device's memory.  out[0] total, out[1] per-sample terms (sample split / grid kernel), out[2] pooled hit
+// records, out[3] the exhaustive pipeline's path state, out[4] stolen samples' rows.
+int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[5]) {
+    if (!scene || !out) {
+        set_last_error("null argument");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    int rc = validate(st, nullptr, 0, opt);
+    if (rc != RTM_OK) return rc;
+    RenderParams P;
+    RenderPlan plan;
+    const SceneView view = scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
+                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt));
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    if (output_rows(opt) == 0) return RTM_OK;
+    rc = plan_render(st, view, scene->n, opt, P, plan);
+    if (rc != RTM_OK) return rc;
+    out[1] = plan.bytes[kScratchTerms];
+    out[2] = plan.bytes[kScratchPool];
+    out[3] = plan.bytes[kScratchWavefront];
+    out[4] = plan.bytes[kScratchSteal];
+    out[0] = out[1] + out[2] + out[3] + out[4];
+    return RTM_OK;
 }
 
 int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
@@ -1899,7 +2174,21 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
         return rc;
     }
-    // device-resident sphere array: flattened on the stream into stream-ordered temporaries, which are
+    // A device-resident array of a size that gets a grid (rtm_scene_create), for the variants that use one: a scene object
+    // made from it — flattened tables + the host-built grid — is kept in a small cache keyed by a hash of the array's
+    // CONTENT, taken on the device behind the stream's queued work (the caller may have written the array there); the call
+    // waits for those 8 bytes.  On a miss the array comes back once for the grid build.  Before round 4 such calls had
+    // no scene object and therefore no grid: the exhaustive pipeline, 118 x the time for BASELINE configs[4].
+    if (n >= kGridMinSpheres && (opt->variant == kVariantAuto || opt->variant == kVariantGrid)) {
+        std::shared_ptr<rtm_scene> sc;
+        rc = cached_device_scene(sp, n, opt->device, stream, &sc);
+        if (rc != RTM_OK) return rc;
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt)),
+                         n, opt, out64, out32, out8, stream, stats);
+        note_scene_use(sc.get(), stream);
+        return rc;
+    }
+    // smaller device-resident arrays: flattened on the stream into stream-ordered temporaries, which are
     // released (hipFreeAsync) behind the render's launches
     keep_stream_ordered_memory(opt->device);
     AsyncMem geom, mat, aux;
@@ -1978,7 +2267,7 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
         set_last_error("band_index outside [0, band_count)");
         return RTM_ERR_INVALID_ARGUMENT;
     }
-    if ((opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_LITERAL && (opt->mode & ~RTM_MODE_HOST_TRIG) != RTM_MODE_REPAIRED) {
+    if ((opt->mode & ~kModeFlags) != RTM_MODE_LITERAL && (opt->mode & ~kModeFlags) != RTM_MODE_REPAIRED) {
         set_last_error("unknown mode");
         return RTM_ERR_INVALID_ARGUMENT;
     }
@@ -2004,7 +2293,7 @@ int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, con
         if (rc != RTM_OK) return rc;
         P.scene.trig_fix = fix;
     }
-    P.mode = opt->mode & ~RTM_MODE_HOST_TRIG;
+    P.mode = opt->mode & ~kModeFlags;
     P.max_bounces = opt->max_bounces;
     P.seed_mult = seed_multiplier(opt->seed);
     if (const char* key = std::getenv("RTM_DEBUG_SEAM_KEY")) {
@@ -2118,8 +2407,12 @@ int math_probe(int op, const double* a, const double* b, size_t n, double* out) 
         rc = ensure_trig_fix(0, &fix);
         if (rc != RTM_OK) return rc;
     }
-    math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da.as<double>(), b ? db.as<double>() : nullptr, n,
-                                                            dout.as<double>(), fix);
+    if (op >= 32) {  // the tolerance row's arithmetic (rtm_kernels_tol.hip)
+        if ((rc = tol_math_probe(op, da.as<double>(), b ? db.as<double>() : nullptr, n, dout.as<double>())) != RTM_OK) return rc;
+    } else {
+        math_probe_kernel<<<(unsigned)((n + 255) / 256), 256>>>(op, da.as<double>(), b ? db.as<double>() : nullptr, n,
+                                                                dout.as<double>(), fix);
+    }
     RTM_HIP_CHECK(hipGetLastError());
     RTM_HIP_CHECK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
     return RTM_OK;

@@ -10,7 +10,7 @@
 
 #include "rtm_path.h"
 
-namespace rtm {
+namespace RTM_NS {
 
 struct RenderParams {
     SceneView scene;
@@ -54,6 +54,9 @@ struct RenderParams {
     // b of a launch renders its tile (b % 8) * xcd_q + min(b % 8, xcd_rem) + b / 8, so that an XCD's blocks cover one
     // contiguous part of the frame and its L2 holds that part's cells (xcd_q = tiles / 8, xcd_rem = tiles % 8)
     unsigned xcd_on, xcd_q, xcd_rem;
+    // the tolerance translation unit (RTM_TOL): per tile of the launch 64 words — bit s of word p: "sub-pixel s of pixel p
+    // has a primary ray whose nearest hit last-bit differences could change" (prim_mask_kernel); null elsewhere
+    const unsigned long long* __restrict__ prim_masks;
 };
 constexpr size_t kTermRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned short);  // 1664 = 13 lines of 128 B
 constexpr size_t kStealRowBytes = 3 * 64 * sizeof(double) + 64 * sizeof(unsigned);       // 1792 = 14 lines of 128 B
@@ -125,10 +128,24 @@ __device__ __forceinline__ D3 primary_dir(const RenderParams& P, int x, int y, i
 // hipcc spill them to scratch per lane (200 MB of stray HBM writes per 1080p frame).
 __device__ __forceinline__ D3 primary_dir_lds(const RenderParams& P, const double* cam, int x, int y, int sx,
                                               int sy) {
+#if RTM_TOL
+    // the tolerance translation unit: the primary ray stays the reference's bit for bit (separately rounded multiplies and
+    // adds, true divisions) — once per S samples, and what rtm_path.h: nearest_hit_exactfp settles exact ties on
+#pragma clang fp contract(off)
+    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
+    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
+    const double vx = (cam[0] * px + cam[3] * py) + cam[6];
+    const double vy = (cam[1] * px + cam[4] * py) + cam[7];
+    const double vz = (cam[2] * px + cam[5] * py) + cam[8];
+    const float len2 = (float)(vx * vx + vy * vy + vz * vz);  // src/Ray.h:67-69
+    const double m = (double)__builtin_sqrtf(len2);
+    return D3{vx / m, vy / m, vz / m};                          // src/Ray.h:70-72
+#else
     const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
     const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
     const D3 ax = d3(cam[0], cam[1], cam[2]), by = d3(cam[3], cam[4], cam[5]), cz = d3(cam[6], cam[7], cam[8]);
     return normalize((ax * px + by * py) + cz);
+#endif
 }
 
 __device__ __forceinline__ void wave_add_counter(unsigned long long* dst, unsigned v) {
@@ -315,6 +332,16 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 
     PathCounters pc = {0, 0, 0};
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
+    // The tolerance translation unit (RTM_TOL, rtm_kernels_tol.hip; STEAL instantiations only): per pixel a bit per sub-pixel —
+    // "the contracted search does not find the reference's hit for this sub-pixel's primary ray" (an exact tie in real
+    // arithmetic: rtm_path.h, nearest_hit_exactfp) —, in LDS so that a lane that steals a sample of another pixel finds it.
+    // Sub-pixels from 64 up have no bit and always take the exact loop.
+    constexpr bool kPrimFix = (RTM_TOL != 0) && STEAL;
+    unsigned long long* prim_mask = reinterpret_cast<unsigned long long*>(fq_pend + 3 * 64);  // behind the two STEAL arrays
+    [[maybe_unused]] bool prim_fix = false;  // this lane's current sample is of a flagged sub-pixel
+    [[maybe_unused]] auto prim_flag_of = [&](const unsigned long long mask, const unsigned sub) {
+        return sub >= 64u || ((mask >> sub) & 1ull) != 0ull;
+    };
     if constexpr (PACKL) {
         if (P.pool) stack.slot = (int)((blockIdx.x * 64u + (unsigned)lane) * 2u);  // two pooled stacks per lane, no allocator
     }
@@ -350,6 +377,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     unsigned n = valid ? n_first : n_end;  // sample index ((sx-1)*SS + (sy-1))*S + s
     int left_in_sub = P.S - (int)(n_first % (unsigned)P.S);  // samples left before the sub-pixel changes
     const int sub_first = (int)(n_first / (unsigned)P.S);
+    if constexpr (kPrimFix) {
+        const unsigned tile_id = (SPLIT && blockIdx.x >= P.split_first) ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles
+                                                                         : blockIdx.x;
+        const unsigned long long mask = P.prim_masks[(size_t)tile_id * 64 + (unsigned)lane];  // prim_mask_kernel, the same launch
+        prim_mask[lane] = mask;
+        prim_fix = prim_flag_of(mask, (unsigned)sub_first);
+    }
     D3 pdir = primary_dir_lds(P, cam, x, y, sub_first / P.SS + 1, sub_first % P.SS + 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
@@ -624,8 +658,23 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             int hit_id;
             const int depth_before = depth;
             PathCounters unused = {0, 0, 0};
-            bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
-                                             trig, &hit_id);
+            bool cont;
+#if RTM_TOL
+            if constexpr (kPrimFix) {
+                double dis;
+                hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+                const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
+                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig,
+                                           flagged, [&](int& id_fix, double& dis_fix) {
+                                               double dis_ref;
+                                               const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
+                                               id_fix = flagged ? id_ref : id_fix;
+                                               dis_fix = flagged ? dis_ref : dis_fix;
+                                           });
+            } else
+#endif
+            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
+                                        trig, &hit_id);
             if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
             // counters (src/Renderer.cpp has none; rtm_stats): one cast per live lane, one draw for the RR test of a
             // hit below the depth cap, two more and a bounce when the path continues
@@ -698,7 +747,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     park[3 * 64 + lane] = pdir.x;
                     park[4 * 64 + lane] = pdir.y;
                     park[5 * 64 + lane] = pdir.z;
+                    if constexpr (kPrimFix) prim_fix = n < n_end && prim_flag_of(prim_mask[lane], (unsigned)sub);
                 }
+                if constexpr (kPrimFix) prim_fix = prim_fix && n < n_end;
                 org = P.cam_org;
                 dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
                 depth = 0;
@@ -730,6 +781,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
           unsigned* st_end = st_next + 64;                               // per pixel: one past its last OWN sample
           const unsigned total = P.total_samples;
           bool busy = n < n_end;                                         // this lane has a path in flight ...
+          if constexpr (kPrimFix) prim_fix = prim_fix && busy;
           unsigned cur = ((unsigned)lane << 16) | (busy ? n : 0u);       // ... of (pixel lane, sample)
           unsigned own_next = busy ? n + 1u : total;
           st_next[lane] = own_next;
@@ -746,7 +798,22 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             int hit_id;
             const int depth_before = depth;
             PathCounters unused = {0, 0, 0};
-            const bool cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig, &hit_id);
+            bool cont;
+#if RTM_TOL
+            if constexpr (kPrimFix) {
+                double dis;
+                hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
+                const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
+                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig,
+                                           flagged, [&](int& id_fix, double& dis_fix) {
+                                               double dis_ref;
+                                               const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
+                                               id_fix = flagged ? id_ref : id_fix;
+                                               dis_fix = flagged ? dis_ref : dis_fix;
+                                           });
+            } else
+#endif
+            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig, &hit_id);
             const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_busy;
             unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_busy;
             if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
@@ -793,6 +860,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 }
                 dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
                 rng = rng_open(pkey, cur & 0xFFFFu);
+                if constexpr (kPrimFix) {
+                    const unsigned s_own = cur & 0xFFFFu;
+                    prim_fix = prim_flag_of(prim_mask[lane], P.S == 1 ? s_own : __umulhi(s_own, P.magic_S));
+                }
             }
             // (2) lanes left without one take the LAST unstarted samples of the pixel that has most to give: what it has
             // not started, but one, and not below the depth the finalize kernel's index covers
@@ -829,6 +900,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         const unsigned sxm1 = P.SS == 1 ? sub : __umulhi(sub, P.magic_SS);
                         dir = primary_dir_lds(P, cam, px, py, (int)sxm1 + 1, (int)(sub - sxm1 * (unsigned)P.SS) + 1);
                         rng = rng_open(vkey, s_st);
+                        if constexpr (kPrimFix) prim_fix = prim_flag_of(prim_mask[v], sub);
                     }
                     if (lane == v) st_end[lane] = e_v - take;
                     claimed += take;
@@ -839,6 +911,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 org = P.cam_org;
                 depth = 0;
                 recq = packed8_empty(P.scene.n);
+                if constexpr (kPrimFix) prim_fix = prim_fix && got;
             }
             if (added != 0u) {
                 fq_tail = (fq_tail + added) & (kFoldRing - 1);
@@ -1064,4 +1137,28 @@ __global__ __launch_bounds__(64) void steal_finalize_kernel(const RenderParams P
     store_pixel(P, valid, px, py, acc);
 }
 
-}  // namespace rtm
+#if RTM_TOL
+// The tolerance translation unit's pre-pass, one wave per tile of the launch, lane = pixel: for every sub-pixel (the first
+// 64 of them) whether its primary ray — shared by its S samples, src/Renderer.cpp:224-232 — is one whose nearest hit
+// last-bit differences could change (rtm_path.h: primary_tie_risk; the shipped Cornell box has such rays along the
+// image's diagonals, where the seam of two wall spheres projects exactly).  The render kernel settles those rays'
+// primary hits with the reference's own arithmetic (nearest_hit_exactfp).
+__global__ __launch_bounds__(64) void prim_mask_kernel(const RenderParams P, unsigned long long* __restrict__ masks) {
+    const int lane = threadIdx.x;
+    const unsigned tile = blockIdx.x;
+    const int x = (int)(tile % (unsigned)P.tiles_x) * 8 + (lane & 7);
+    const int y = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);
+    const double cam[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
+    SceneGlobal sc;
+    sc.v = P.scene;
+    unsigned long long mask = 0ull;
+    const unsigned subs = (unsigned)(P.SS * P.SS) < 64u ? (unsigned)(P.SS * P.SS) : 64u;
+    for (unsigned sub = 0; sub < subs; ++sub) {
+        const D3 d = primary_dir_lds(P, cam, x, y, (int)(sub / (unsigned)P.SS) + 1, (int)(sub % (unsigned)P.SS) + 1);
+        mask |= primary_tie_risk(sc, P.cam_org, d) ? (1ull << sub) : 0ull;
+    }
+    masks[(size_t)tile * 64 + (unsigned)lane] = mask;
+}
+#endif
+
+}  // namespace RTM_NS

@@ -159,8 +159,7 @@ class StripRenderer:
 
     def __init__(self, data, rank=0, world=1, device=0, mode="repaired", max_bounces=-1,
                  seed=0x5EED, variant=0, want="f32", rows=None, layout="bands", host_trig=True,
-                 force_collective=False):
-        from .renderer import Renderer
+                 force_collective=False, renderer=None):
         if layout not in ("bands", "strips"):
             raise ValueError(f"unknown layout {layout!r}")
         self.data, self.rank, self.world, self.layout = data, rank, world, layout
@@ -172,9 +171,13 @@ class StripRenderer:
         # world == 1 normally skips the gather; force_collective sends the frame through the process
         # group anyway (the one-rank RCCL rehearsal of the N-rank step)
         self.force_collective = bool(force_collective)
-        self.renderer = Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, device=device,
-                                 variant=variant, host_trig=host_trig)
+        if renderer is None:  # (`renderer`: a stand-in with render_rows_device, for the CPU rehearsal of the N-rank step)
+            from .renderer import Renderer
+            renderer = Renderer(data, mode=mode, max_bounces=max_bounces, seed=seed, device=device,
+                                variant=variant, host_trig=host_trig)
+        self.renderer = renderer
         self.image = None  # assembled frame on rank 0 after step()
+        self.local = None  # this rank's rows of the last step (band stack or strip)
 
     def step(self, stats=False, events=None):
         """Render this rank's strip into HBM, then gather the strips on rank 0."""
@@ -189,11 +192,86 @@ class StripRenderer:
                                                        stats=stats)
         if events is not None:
             events[1].record()
-        local = out[self.want]
+        self.local = out[self.want]
+        self.gather()
+        return st
+
+    def gather(self):
+        """The end-of-step collective alone, on the rows of the last step: rank 0 gets the assembled frame."""
+        local = self.local
         if self.world == 1 and not self.force_collective:
             self.image = local
         elif self.layout == "bands":
             self.image = gather_bands(local, self.range[0], self.range[1], self.rank, self.world)
         else:
             self.image = gather_strips(local, self.strips, self.rank, self.world)
-        return st
+        return self.image
+
+    def single_gpu_frame(self):
+        """The whole row range rendered by THIS rank alone, in one launch — what the assembled frame must equal bit
+        for bit (the RNG is keyed by the global pixel index: tiling must not change any sample)."""
+        out, _ = self.renderer.render_rows_device(self.range[0], self.range[1], want=(self.want,), stats=False)
+        return out[self.want]
+
+
+def frames_equal_bitwise(a, b):
+    """Two frames (torch tensors of one dtype and shape, any device) hold the same BITS (NaNs included)."""
+    import torch
+    if a is None or b is None or a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    view = {torch.float32: torch.int32, torch.float64: torch.int64}.get(a.dtype)
+    a, b = a.detach().cpu(), b.detach().cpu()
+    return bool(torch.equal(a.view(view), b.view(view))) if view else bool(torch.equal(a, b))
+
+
+def multi_gpu_evidence(sr, stats, kernel_ms, steps, barrier, use_group=True):
+    """What lets an N-rank bench line prove itself (all of it OUTSIDE the timed region; every rank calls this):
+      frame_matches_single_gpu  rank 0 renders the whole row range alone, in one launch on its own GPU, and compares the
+                                frame the ranks assembled with it bit for bit;
+      per_rank                  every rank's kernel time, rows, samples, casts, bounces and draws of the instrumented
+                                step (load balance; their sums are the frame's counters);
+      gather_ms                 the end-of-step collective alone (the rows of the last step gathered `steps` more times,
+                                barrier + synchronise on both sides, slowest rank).
+    Returns the dict on rank 0 and None elsewhere."""
+    import time
+    import torch
+    import torch.distributed as dist
+    rows = int(sr.local.shape[0]) if sr.local is not None else 0
+    mine = torch.tensor([float(kernel_ms), float(rows)] + [float(stats[k]) for k in ("samples", "casts", "bounces", "draws")],
+                        dtype=torch.float64)
+    world = sr.world
+    if use_group:
+        on = sr.local.device if (sr.local is not None and dist.get_backend() == "nccl") else "cpu"
+        parts = [torch.zeros_like(mine, device=on) for _ in range(world)]
+        dist.all_gather(parts, mine.to(on))
+        parts = [p.cpu() for p in parts]
+    else:
+        parts = [mine]
+    per_rank = [{"rank": r, "kernel_ms": float(p[0]), "rows": int(p[1]), "samples": int(p[2]), "casts": int(p[3]),
+                 "bounces": int(p[4]), "draws": int(p[5])} for r, p in enumerate(parts)]
+    assembled = sr.image  # rank 0: the frame of the last step
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, steps)):
+        sr.gather()
+    barrier()
+    gather_ms = (time.perf_counter() - t0) / max(1, steps) * 1e3
+    t = torch.tensor([gather_ms], dtype=torch.float64)
+    if use_group:
+        t = t.to(on)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gather_ms = float(t[0])
+    match = None
+    if sr.rank == 0:
+        match = frames_equal_bitwise(assembled, sr.single_gpu_frame())
+    barrier()
+    if sr.rank != 0:
+        return None
+    total = {k: sum(p[k] for p in per_rank) for k in ("rows", "samples", "casts", "bounces", "draws")}
+    slowest = max(p["kernel_ms"] for p in per_rank)
+    mean = sum(p["kernel_ms"] for p in per_rank) / len(per_rank)
+    return {"frame_matches_single_gpu": match, "per_rank": per_rank, "totals": total, "gather_ms": gather_ms,
+            "kernel_ms_slowest_over_mean": slowest / mean if mean > 0 else None,
+            "how": "rank 0 re-rendered the whole row range alone (one launch) and compared the gathered frame with it bit "
+                   "for bit; per_rank from the instrumented step; gather_ms = the collective alone, slowest rank; all "
+                   "outside the timed region"}

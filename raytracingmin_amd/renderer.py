@@ -21,12 +21,13 @@ from .settings import SettingData
 
 class Renderer:
     def __init__(self, data: SettingData, mode="repaired", max_bounces=-1, seed=0x5EED, device=0,
-                 variant=0, host_trig=True):
+                 variant=0, host_trig=True, count_tests=False):
         # host_trig (default): sin/cos of src/Renderer.cpp:93-94 as the HOST's libm returns them, so a
         # render agrees with a CPU run of the reference bit for bit even on scenes that amplify one-ulp
         # differences over many bounces; host_trig=False is the labelled ~2 % faster device-trig row
         self.data = data  # the reference keeps a reference to the caller's SettingData
-        self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0)
+        # count_tests: rtm_stats.object_tests also for the uniform-grid kernel (its counting instantiation, RTM_MODE_COUNT_TESTS)
+        self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0) | (_lib.MODE_COUNT_TESTS if count_tests else 0)
         self.max_bounces = int(max_bounces)
         self.seed = int(seed)
         self.device = int(device)
@@ -58,6 +59,15 @@ class Renderer:
                 _lib.check(_lib.lib().rtm_scene_create(arr, n, 0, self.device, C.byref(h)), "rtm_scene_create")
             self._scene, self._scene_key = h, key
         return self._scene
+
+    def scratch_bytes(self, row_begin=0, row_end=None, band=None):
+        """rtm_scratch_bytes: what a render of these rows asks of the library's per-(device, stream) work buffers."""
+        row_end = self.data.height if row_end is None else row_end
+        opt = self._options(row_begin, row_end, band)
+        st = self.data.settings_c()
+        out = (C.c_uint64 * 5)()
+        _lib.check(_lib.lib().rtm_scratch_bytes(C.byref(st), self._scene_handle(), C.byref(opt), out), "rtm_scratch_bytes")
+        return dict(zip(("total", "terms", "records", "pipeline_state", "steal_rows"), (int(v) for v in out)))
 
     def invalidate(self):
         if self._scene is not None:

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), f"{n} declared in include/rtm.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().rtm_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().rtm_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_exported_symbols_are_exactly_the_two_headers():
@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.rtm_sphere) == 80
     assert C.sizeof(_lib.rtm_settings) == 96
     assert C.sizeof(_lib.rtm_options) == 40
-    assert C.sizeof(_lib.rtm_stats) == 48
+    assert C.sizeof(_lib.rtm_stats) == 56
     assert C.sizeof(_lib.rtm_object) == 136
     # the oracle's view of the same PODs
     import _oracle

@@ -116,3 +116,69 @@ def test_gather_strips_and_bands_gloo(world, height):
     r, c, ch = np.meshgrid(np.arange(height), np.arange(width), np.arange(3), indexing="ij")
     assert np.array_equal(img, (r * 10000 + c * 10 + ch).astype(np.float32))
     assert np.array_equal(img_bands, (r * 10000 + c * 10 + ch).astype(np.float32))
+
+
+class _FakeRenderer:
+    """Stand-in for raytracingmin_amd.Renderer on a machine without a GPU: a "pixel" is a function of its GLOBAL row and
+    column (like the real one, whose RNG is keyed by the global pixel index), rendered into CPU tensors.  `bad_rank`
+    corrupts one pixel of that rank's band part — the proof must notice."""
+
+    def __init__(self, width, rank, bad_rank=None):
+        self.width, self.rank, self.bad_rank = width, rank, bad_rank
+
+    def render_rows_device(self, row_begin=0, row_end=None, want=("f32",), stats=True, stream=None, band=None):
+        rows = band_row_index(row_begin, row_end, band[0], band[1]) if band else np.arange(row_begin, row_end)
+        r = torch.as_tensor(rows, dtype=torch.float32).view(-1, 1, 1)
+        cols = torch.arange(self.width, dtype=torch.float32).view(1, -1, 1)
+        ch = torch.arange(3, dtype=torch.float32).view(1, 1, 3)
+        img = torch.sin(r * 12.9898 + cols * 78.233 + ch)  # any deterministic function of the global pixel
+        if band and self.bad_rank == self.rank and len(rows):
+            img[0, 0, 0] += 1e-6
+        n = len(rows) * self.width
+        st = {"samples": n * 4, "casts": n * 9 + self.rank, "bounces": n * 5, "draws": n * 19, "kernel_ms": 1.0 + self.rank,
+              "variant": 2, "split": 1}
+        return {want[0]: img}, (st if stats else None)
+
+    def stream_status(self, stream=None):
+        pass
+
+
+def _evidence_worker(rank, world, port, height, width, bad_rank, q):
+    from raytracingmin_amd.distributed import StripRenderer, multi_gpu_evidence
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sr = StripRenderer(None, rank=rank, world=world, rows=(0, height), renderer=_FakeRenderer(width, rank, bad_rank))
+        stats = sr.step(stats=True)
+        ev = multi_gpu_evidence(sr, stats, stats["kernel_ms"], steps=2, barrier=dist.barrier)
+        if rank == 0:
+            q.put(ev)
+        else:
+            assert ev is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bad_rank", [(2, None), (2, 1), (3, None)])
+def test_multi_gpu_evidence_keys_gloo(world, bad_rank):
+    """What bench.py --gpus N puts into its line so that an N-rank run proves itself: the assembled frame
+    compared bit for bit with rank 0's own single-launch render, every rank's kernel time / rows / counters, the gather
+    alone timed.  World 2 and 3 over gloo with a stand-in renderer; a corrupted part must flip the flag."""
+    height, width = 45, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_evidence_worker, args=(r, world, port, height, width, bad_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    (ev,) = _collect(procs, q, 1)
+    assert ev["frame_matches_single_gpu"] is (bad_rank is None)
+    assert [p["rank"] for p in ev["per_rank"]] == list(range(world))
+    assert sum(p["rows"] for p in ev["per_rank"]) == height == ev["totals"]["rows"]
+    for p in ev["per_rank"]:
+        assert p["rows"] == len(band_row_index(0, height, world, p["rank"]))
+        assert p["kernel_ms"] == 1.0 + p["rank"] and p["samples"] == p["rows"] * width * 4
+        assert p["casts"] == p["rows"] * width * 9 + p["rank"]
+    assert ev["gather_ms"] > 0.0 and ev["kernel_ms_slowest_over_mean"] >= 1.0

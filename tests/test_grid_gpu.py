@@ -326,8 +326,10 @@ print(st["casts"])
 def test_grid_through_every_entry_point(rtm, oracle):
     """A 2 000-sphere scene through the C ABI's entry points: a scene object made from a HOST array and one made from a
     DEVICE array (its geometry rows come back once for the host-side grid build) both render through the grid
-    (rtm_stats.variant 17); the array entry points use the scene cache for a host array (grid) and per-call tables for a
-    device array (no scene object: the exhaustive pipeline) — one frame, bit for bit, from all of them."""
+    (rtm_stats.variant 17); so do the array entry points — a host array through the content-addressed scene cache, a device
+    array through the cache keyed by a hash of its content taken on the device (round 3 gave it per-call tables and the
+    exhaustive pipeline: 118 x the time for BASELINE configs[4]) — one frame, bit for bit, from all of them; the device
+    array's content changed in place is noticed."""
     import ctypes as C
     import torch
     L = rtm.lib()
@@ -356,9 +358,18 @@ def test_grid_through_every_entry_point(rtm, oracle):
         frame(lambda o, s: L.rtm_render_device(C.byref(st), arr, n, 0, C.byref(opt), o, None, None, stream, s)),
         frame(lambda o, s: L.rtm_render_device(C.byref(st), C.c_void_p(d_arr.data_ptr()), n, 1, C.byref(opt), o, None, None, stream, s)),
     ]
-    assert [v for _, v, _ in results] == [17, 17, 17, 12]
+    assert [v for _, v, _ in results] == [17, 17, 17, 17]
     for f, _, casts in results:
         assert np.array_equal(f.view(np.uint64), ref.view(np.uint64)) and casts == cnt["casts"]
+    # the same device pointer, other content: sphere 5 becomes a big bright ball in front of the camera
+    arr[5].center[0], arr[5].center[1], arr[5].center[2], arr[5].radius = 0.0, 0.0, -40.0, 6.0
+    arr[5].emission[0] = arr[5].emission[1] = arr[5].emission[2] = 3.0
+    d_arr.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
+    ost2, oarr2 = ost, (oracle.Sphere * n).from_buffer_copy(bytes(arr))
+    ref2, cnt2 = oracle.render(ost2, oarr2, n, oracle.make_options(mode=1, max_bounces=8, seed=3, height=40))
+    f2, v2, casts2 = frame(lambda o, s: L.rtm_render_device(C.byref(st), C.c_void_p(d_arr.data_ptr()), n, 1, C.byref(opt), o, None, None, stream, s))
+    assert v2 == 17 and casts2 == cnt2["casts"] and not np.array_equal(ref2, ref)
+    assert np.array_equal(f2.view(np.uint64), ref2.view(np.uint64))
     assert L.rtm_scene_destroy(h_host) == 0 and L.rtm_scene_destroy(h_dev) == 0
 
 
@@ -378,3 +389,114 @@ def test_environment_sphere_keeps_variant_0_off_the_grid(rtm, oracle):
         assert (st0["variant"] == 17) == expect_grid and st17["variant"] == 17
         assert np.array_equal(auto["f64"].view(np.uint64), ref.view(np.uint64)) and st0["casts"] == cnt["casts"]
         assert np.array_equal(named["f64"].view(np.uint64), ref.view(np.uint64)) and st17["casts"] == cnt["casts"]
+
+
+def test_grid_deep_paths_take_pooled_records_of_the_kernels_own_type(rtm, oracle):
+    """Unlimited depth through the grid kernel with MORE lanes going deeper than its 32 on-chip levels than a byte-sized
+    pool would hold: the grid kernel is instantiated for 4-byte records whatever the scene's size, and the pooled stack
+    must be sized for those (round 3 sized it from n <= 256: slot 16 384's first push landed on the slot counter).  A
+    closed box of six wall spheres with kd 0.98 around 100 bright-coloured small spheres: the mean path is ~50 casts
+    long, 24 576 lanes, every one of them deeper than 32 levels at some point."""
+    rng = np.random.default_rng(77)
+    data = rtm.SettingData()
+    data.width, data.height, data.samples, data.superSamples = 192, 128, 3, 1
+    data.camera = rtm.Camera(rtm.vec3(0, 0, -9.0), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.2)
+    wall = rtm.vec3(0.98, 0.98, 0.98)
+    R = 1.0e4
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            c = [0.0, 0.0, 0.0]
+            c[axis] = sign * (R + 10.0)
+            data.object.append(rtm.SphereObject(rtm.vec3(*c), R, rtm.Material(wall, rtm.vec3(0, 0, 0))))
+    for i in range(100):
+        c = rng.uniform(-8.0, 8.0, 3)
+        col = rng.uniform(0.9, 0.98, 3)
+        em = (4.0, 4.0, 4.0) if i % 25 == 0 else (0.0, 0.0, 0.0)
+        data.object.append(rtm.SphereObject(rtm.vec3(*c), float(rng.uniform(0.4, 1.0)), rtm.Material(rtm.vec3(*col), rtm.vec3(*em))))
+    ost, oarr, n = _oracle_view(oracle, data)
+    ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=-1, seed=21, height=data.height))
+    assert cnt["max_depth"] > 200 and cnt["casts"] / cnt["samples"] > 30
+    for variant in (17, 0):
+        out, st = _image(rtm, data, "repaired", -1, 21, variant)
+        assert st["variant"] == 17
+        assert np.array_equal(out["f64"].view(np.uint64), ref.view(np.uint64)), variant
+        assert (st["casts"], st["bounces"], st["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"])
+
+
+def _plane_scene(rtm, n_spheres, seed):
+    """A room of six png::PlaneObject walls (kd 0.75, the ceiling emissive) around `n_spheres` random spheres."""
+    rng = np.random.default_rng(seed)
+    data = rtm.SettingData()
+    data.camera = rtm.Camera(rtm.vec3(0, 0, -19.0), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.0)
+    grey, light = rtm.vec3(0.75, 0.75, 0.75), rtm.vec3(0.5, 0.5, 0.5)
+    half = 20.0
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            pos = [0.0, 0.0, 0.0]
+            pos[axis] = sign * half
+            up = rtm.vec3(0, 0, 1) if axis == 1 else rtm.vec3(0, 1, 0)
+            em = rtm.vec3(2.0, 2.0, 2.0) if (axis == 1 and sign > 0) else rtm.vec3(0, 0, 0)
+            data.object.append(rtm.PlaneObject(rtm.vec3(*pos), up, rtm.vec3(0, 0, 0), 2.0 * half, rtm.Material(light if em.x else grey, em)))
+    for i in range(n_spheres):
+        c = rng.uniform(-16.0, 16.0, 3)
+        col = rng.uniform(0.2, 0.9, 3)
+        em = (5.0, 5.0, 5.0) if i % 40 == 0 else (0.0, 0.0, 0.0)
+        data.object.insert(int(rng.integers(0, len(data.object) + 1)),  # planes anywhere in the vector: the index decides ties
+                           rtm.SphereObject(rtm.vec3(*c), float(rng.uniform(0.3, 1.2)), rtm.Material(rtm.vec3(*col), rtm.vec3(*em))))
+    return data
+
+
+@pytest.mark.parametrize("n_spheres,mb", [(300, 8), (300, -1), (1500, 8)])
+def test_grid_serves_scenes_with_planes(rtm, oracle, n_spheres, mb):
+    """Scenes of 256 objects and more that hold png::PlaneObject entries (src/SettingData.cpp:235-249, this build's
+    completion) had only the per-object loop (variant 1); now they get the grid over their spheres, with the planes
+    among the objects every ray tests, next to the spheres that span the scene — the oracle's frame and counters through
+    variant 0 and variant 17, and the per-object loop's."""
+    data = _plane_scene(rtm, n_spheres, seed=n_spheres + 7)
+    data.width, data.height, data.samples, data.superSamples = 72, 48, 3, 1
+    arr, n = data.objects_c()
+    st = data.settings_c()
+    ost = oracle.Settings.from_buffer_copy(bytes(st))
+    oarr = (oracle.Object * n).from_buffer_copy(bytes(arr))
+    ref, cnt = oracle.render_objects(ost, oarr, n, oracle.make_options(mode=1, max_bounces=mb, seed=9, height=data.height))
+    assert ref.any()
+    for variant in (0, 17, 1):
+        out, stt = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=9, variant=variant).render_rows_device(want=("f64", "u8"))
+        assert stt["variant"] == (1 if variant == 1 else 17), (variant, stt["variant"])
+        assert np.array_equal(out["f64"].cpu().numpy().view(np.uint64), ref.view(np.uint64)), variant
+        assert np.array_equal(out["u8"].cpu().numpy(), oracle.quantise(ref))
+        assert (stt["casts"], stt["bounces"], stt["draws"]) == (cnt["casts"], cnt["bounces"], cnt["draws"])
+    lit, _ = rtm.Renderer(data, mode="literal", max_bounces=mb, seed=9).render_rows_device(want=("f64",))
+    lit_ref, _ = oracle.render_objects(ost, oarr, n, oracle.make_options(mode=0, max_bounces=mb, seed=9, height=data.height))
+    assert np.array_equal(lit["f64"].cpu().numpy().view(np.uint64), lit_ref.view(np.uint64))
+
+
+def test_grid_counts_its_sphere_tests_and_scratch_is_announced(rtm, oracle):
+    """RTM_MODE_COUNT_TESTS: the grid kernel's counting instantiation reports the Intersect evaluations it made
+    (rtm_stats.object_tests) — the same frame and counters as the plain one, a small fraction of casts x n —, the exhaustive
+    kernels report casts x n.  rtm_scratch_bytes announces the work buffers of a render before anything is allocated."""
+    data = rtm.make_stress_scene(n=20_000, seed=4)
+    data.width, data.height, data.samples, data.superSamples = 160, 96, 8, 1
+    plain, ps = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2).render_rows_device(want=("f64",))
+    counted, cs = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2, count_tests=True).render_rows_device(want=("f64",))
+    assert ps["variant"] == cs["variant"] == 17 and ps["object_tests"] == 0
+    assert np.array_equal(plain["f64"].cpu().numpy().view(np.uint64), counted["f64"].cpu().numpy().view(np.uint64))
+    assert cs["casts"] == ps["casts"]
+    per_cast = cs["object_tests"] / cs["casts"]
+    print(f"20 000 spheres: {per_cast:.1f} sphere tests per cast through the grid (the reference's loop: 20 000)")
+    assert 1.0 < per_cast < 200.0
+    strip, xs = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2, variant=12).render_rows_device(40, 48, want=("f64",))
+    assert xs["object_tests"] == xs["casts"] * 20_000
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2)
+    sb = r.scratch_bytes()
+    tiles = (160 // 8) * (96 // 8)
+    assert sb["terms"] == tiles * 8 * 64 * 32 and sb["records"] == 0 and sb["total"] == sb["terms"]
+    deep = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=2).scratch_bytes()
+    assert deep["records"] == 65536 * 960 * 4 + 64  # the grid kernel's records are 4 bytes wide whatever n
+    x = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2, variant=12).scratch_bytes()
+    assert x["pipeline_state"] > 160 * 96 * 150 and x["terms"] == 0
+    cornell = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    cornell.width, cornell.height, cornell.samples, cornell.superSamples = 1920, 1080, 64, 4
+    head = rtm.Renderer(cornell, mode="repaired", max_bounces=8, seed=2).scratch_bytes()
+    print("headline frame:", {k: f"{v / 2**30:.2f} GiB" for k, v in head.items()})
+    assert head["terms"] > 2**30 and head["steal_rows"] > 2**31 and head["records"] == 0

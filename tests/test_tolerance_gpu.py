@@ -1,0 +1,177 @@
+"""The fp64 TOLERANCE row (rtm_options.variant 18, csrc/rtm_kernels_tol.hip): the default kernel's source compiled with FMA
+contraction and one-ulp division / square root, float islands, RNG, thresholds and the order of the additions kept.
+
+north_star's bar is a per-pixel delta of 1e-4 against the CPU renderer; the default kernels meet it with 0.  This row is
+asserted against THAT bar — max per-pixel |delta| <= 1e-4 against the exact kernel's frame, which is the oracle's
+(tests/test_parity_gpu.py) — and every test prints how many pixels differ at all and whether the counters agree: on the
+Cornell box a sample's value is a function of its path's hit ids (the fold is kept unfused), so the expected difference is
+zero pixels unless a last-bit change of a distance flips which sphere a ray hits."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NORTH_STAR_TOL = 1e-4
+TOL_VARIANT = 18
+
+
+@pytest.fixture(scope="module")
+def rtm():
+    import raytracingmin_amd as m
+    return m
+
+
+def _probe(rtm, op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        bp = b.ctypes.data
+    rtm._lib.check(rtm.lib().rtm_debug_math_probe(op, a.ctypes.data, bp, a.size, out.ctypes.data), "probe")
+    return out
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))  # same sign assumed
+
+
+def test_tolerance_arithmetic_is_within_its_stated_ulps(rtm):
+    """csrc/rtm_path.h seq_sqrt / seq_rcp / seq_quot as this row compiles them: square root and reciprocal within one
+    ulp of the correctly rounded value, the quotient within two; x * y + 1 IS contracted here (and is not in the exact
+    translation unit: test_device_primitives_vs_host_libm), the fold step is NOT."""
+    rng = np.random.default_rng(11)
+    n = 1 << 21
+    x = np.concatenate([rng.uniform(0, 4, n), 10.0 ** rng.uniform(-12, 12, n), rng.uniform(2.0 ** -24, 1, n)])
+    y = 10.0 ** rng.uniform(-6, 6, x.size) * rng.choice([-1.0, 1.0], x.size)
+    worst = {}
+    for name, op, got_args, want, bound in (("sqrt", 32, (x,), np.sqrt(x), 1), ("rcp", 34, (y,), 1.0 / y, 1),
+                                            ("quotient", 33, (x, y), x / y, 2)):
+        u = _ulps(_probe(rtm, op, *got_args), want)
+        worst[name] = (int(u.max()), float((u != 0).mean()))
+        assert u.max() <= bound, (name, int(u.max()))
+    print("tolerance arithmetic, worst ulp distance and share of results that are not the correctly rounded one:", worst)
+    import math
+    fused = _probe(rtm, 35, x, y)
+    want_fused = np.array([math.fma(a, b, 1.0) for a, b in zip(x[:20000], y[:20000])]) if hasattr(math, "fma") else None
+    unfused = x * y + 1.0
+    assert (fused != unfused).any(), "this translation unit is compiled with contraction"
+    if want_fused is not None:
+        assert np.array_equal(fused[:20000], want_fused)
+    # one level of the fold, L = colorKD * L + emission: separately rounded in BOTH translation units
+    assert np.array_equal(_probe(rtm, 38, x, y), x * y + 0.25)
+    # sin / cos of r1 = 2 pi u: at most one ulp from the exact unit's (the sequence has explicit FMAs already)
+    u = (2 * rng.integers(0, 1 << 23, n) + 1) / 16777216.0
+    r1 = 6.283185307179586 * u
+    for op_tol, op_exact in ((36, 12), (37, 13)):
+        a, b = _probe(rtm, op_tol, r1), _probe(rtm, op_exact, r1)
+        assert np.max(np.abs(a - b)) <= 2.3e-16
+
+
+def _frames(rtm, data, mb, seed, rows=None, band=None):
+    rb, re = rows if rows else (0, data.height)
+    exact, es = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=seed).render_rows_device(rb, re, want=("f64", "u8"), band=band)
+    tol, ts = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=seed, variant=TOL_VARIANT).render_rows_device(
+        rb, re, want=("f64", "u8"), band=band)
+    assert ts["variant"] == TOL_VARIANT and es["variant"] == 2
+    return exact, es, tol, ts
+
+
+def _report(label, exact, es, tol, ts):
+    a, b = exact["f64"].cpu().numpy(), tol["f64"].cpu().numpy()
+    delta = np.abs(a - b)
+    worst = float(np.nanmax(delta)) if delta.size else 0.0
+    differing = int((a.view(np.uint64) != b.view(np.uint64)).any(axis=-1).sum())
+    out = int((delta.max(axis=-1) > NORTH_STAR_TOL).sum())
+    u8_diff = int((exact["u8"].cpu().numpy() != tol["u8"].cpu().numpy()).any(axis=-1).sum())
+    same_counters = all(es[k] == ts[k] for k in ("samples", "casts", "bounces", "draws"))
+    print(f"{label}: tolerance row {ts['kernel_ms']:.2f} ms against {es['kernel_ms']:.2f} ms exact "
+          f"({es['kernel_ms'] / ts['kernel_ms']:.3f}x); pixels that differ at all {differing} of {a.shape[0] * a.shape[1]}, "
+          f"outside 1e-4: {out}, 8-bit pixels that differ {u8_diff}, max |delta| {worst:.3e}, "
+          f"casts/bounces/draws {'equal' if same_counters else 'DIFFER'}")
+    return worst, differing, same_counters
+
+
+def test_tolerance_row_on_the_baseline_cornell_configs(rtm, oracle):
+    """BASELINE configs[1] whole (512x512 @ 256 spp, cap 8), configs[2] whole (1920x1080 @ 1024 spp, cap 8 — the headline
+    frame) and one of the eight band parts of configs[3] (3840x2160 @ 4096 spp): max per-pixel |delta| <= 1e-4 against
+    the exact kernel's frame (the oracle's, bit for bit: test_config2_full_frame_vs_oracle, test_headline_config_strip_
+    vs_oracle, test_config4_band_parts_vs_oracle)."""
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    data = rtm.LoadData(scene).data
+    for label, (w, h, s, ss), band in (("configs[1] 512x512 @ 256 spp", (512, 512, 16, 4), None),
+                                       ("configs[2] 1920x1080 @ 1024 spp (headline)", (1920, 1080, 64, 4), None),
+                                       ("configs[3] 3840x2160 @ 4096 spp, band part 3 of 8", (3840, 2160, 256, 4), (8, 3))):
+        data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+        worst, differing, same = _report(label, *_frames(rtm, data, 8, 0x5EED, band=band))
+        assert worst <= NORTH_STAR_TOL, label
+    # a row of the headline frame against the oracle itself (no exact kernel in between)
+    data.width, data.height, data.samples, data.superSamples = 1920, 1080, 64, 4
+    st, arr, n = oracle.load_scene(scene, width=1920, height=1080, samples=64, super_samples=4)
+    ref, _ = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=8, seed=0x5EED, row_begin=539, row_end=540))
+    row, _ = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=0x5EED, variant=TOL_VARIANT).render_rows_device(539, 540, want=("f64",))
+    assert float(np.max(np.abs(row["f64"].cpu().numpy() - ref))) <= NORTH_STAR_TOL
+
+
+@pytest.mark.parametrize("scene,w,h,s,ss,mb", [("cornellBoxSetting.json", 96, 64, 4, 2, 8), ("simpleSetting1.json", 80, 48, 16, 1, 8),
+                                               ("simpleSetting2.json", 64, 64, 3, 1, 4), ("settingData.json", 100, 52, 5, 2, 0),
+                                               ("cornellBoxSetting.json", 400, 328, 8, 2, 8)])
+def test_tolerance_row_small_frames_vs_oracle(rtm, oracle, scene, w, h, s, ss, mb):
+    """Every shipped scene against the ORACLE within 1e-4, through the paths the row has: a launch small enough to be
+    split whole, odd sample counts (no stealing under 16 spp: the row's stealing-free path), a launch of whole and split
+    tiles (400x328), a row range and a band part."""
+    path = oracle.scene_path(scene)
+    data = rtm.LoadData(path).data
+    data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+    st, arr, n = oracle.load_scene(path, width=w, height=h, samples=s, super_samples=ss)
+    ref, cnt = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=mb, seed=7, height=h))
+    r = rtm.Renderer(data, mode="repaired", max_bounces=mb, seed=7, variant=TOL_VARIANT)
+    out, stats = r.render_rows_device(want=("f64",))
+    img = out["f64"].cpu().numpy()
+    assert stats["variant"] == TOL_VARIANT
+    assert float(np.max(np.abs(img - ref))) <= NORTH_STAR_TOL
+    differing = int((img.view(np.uint64) != ref.view(np.uint64)).any(axis=-1).sum())
+    print(f"{scene} {w}x{h} @ {s * ss * ss} spp cap {mb}: {differing} pixels differ from the oracle at all; casts "
+          f"{stats['casts']} vs {cnt['casts']}")
+    assert abs(stats["casts"] - cnt["casts"]) <= max(2, cnt["casts"] // 100000)
+    part, _ = r.render_rows_device(8, h - 8, want=("f64",))
+    assert float(np.max(np.abs(part["f64"].cpu().numpy() - ref[8:h - 8]))) <= NORTH_STAR_TOL
+    from raytracingmin_amd.distributed import band_row_index
+    band, _ = r.render_rows_device(0, h, want=("f64",), band=(3, 1))
+    assert float(np.max(np.abs(band["f64"].cpu().numpy() - ref[band_row_index(0, h, 3, 1)]))) <= NORTH_STAR_TOL
+    # literal mode (HEAD as shipped): RNG-independent, the exact kernel's bits
+    lit, _ = rtm.Renderer(data, mode="literal", max_bounces=mb, seed=7, variant=TOL_VARIANT).render_rows_device(want=("f64",))
+    lit_ref, _ = oracle.render(st, arr, n, oracle.make_options(mode=0, max_bounces=mb, seed=7, height=h))
+    assert float(np.nanmax(np.abs(lit["f64"].cpu().numpy() - lit_ref))) <= NORTH_STAR_TOL
+
+
+def test_tolerance_row_without_stealing_and_what_it_refuses(rtm, oracle):
+    """RTM_DEBUG_TOL_NOSTEAL: the row's stealing-free path on a frame that would steal — the same frame as with stealing
+    (stealing only reorders who traces a sample).  Scenes the row does not serve are refused, never rendered by something
+    else under its name."""
+    path = oracle.scene_path("cornellBoxSetting.json")
+    data = rtm.LoadData(path).data
+    data.width, data.height, data.samples, data.superSamples = 128, 96, 16, 2
+    r = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=3, variant=TOL_VARIANT)
+    with_steal, s1 = r.render_rows_device(want=("f64",))
+    os.environ["RTM_DEBUG_TOL_NOSTEAL"] = "1"
+    try:
+        without, s2 = r.render_rows_device(want=("f64",))
+    finally:
+        del os.environ["RTM_DEBUG_TOL_NOSTEAL"]
+    assert np.array_equal(with_steal["f64"].cpu().numpy().view(np.uint64), without["f64"].cpu().numpy().view(np.uint64))
+    assert s1["casts"] == s2["casts"]
+    for kwargs in (dict(max_bounces=-1), dict(max_bounces=9)):
+        with pytest.raises(rtm.RtmError, match="variant 18"):
+            rtm.Renderer(data, mode="repaired", seed=3, variant=TOL_VARIANT, **kwargs).render_rows_device(want=("f64",))
+    big = rtm.make_stress_scene(n=40, seed=1)
+    big.width, big.height, big.samples, big.superSamples = 16, 16, 1, 1
+    with pytest.raises(rtm.RtmError, match="variant 18"):
+        rtm.Renderer(big, mode="repaired", max_bounces=8, seed=3, variant=TOL_VARIANT).render_rows_device(want=("f64",))
+    room = rtm.LoadData(oracle.scene_path("planeRoom.json")).data
+    room.width, room.height, room.samples, room.superSamples = 16, 16, 1, 1
+    with pytest.raises(rtm.RtmError):
+        rtm.Renderer(room, mode="repaired", max_bounces=8, seed=3, variant=TOL_VARIANT).render_rows_device(want=("f64",))
