@@ -109,7 +109,15 @@ enum { RTM_MODE_LITERAL = 0,  /* L0: HEAD as shipped (normal lost, recursion get
        /* flag, OR-ed into mode (diagnostic): a render WITH rtm_stats also counts the Intersect evaluations it makes
         * (rtm_stats.object_tests).  The exhaustive kernels make n_objects per cast by construction; the uniform-grid kernel
         * (variant 17) runs a counting instantiation that is a few per cent slower, so time a frame without the flag.     */
-       RTM_MODE_COUNT_TESTS = 0x200 };
+       RTM_MODE_COUNT_TESTS = 0x200,
+       /* flag, OR-ed into mode: the INTEGRATOR is png::SurfaeSample (src/Renderer.cpp:119-198 with
+        * SphereObject::ComputeSurfacePoint, src/SettingData.cpp:227-233) instead of png::PathTracing — the branch
+        * src/Renderer.cpp:234-236 takes when a U[0,1) draw is >= 1.0, i.e. never in the reference; the function is defined,
+        * has external linkage and takes the same injectable generator, so it is restated (oracle first) and served by a
+        * general per-object kernel, not by the tuned ones.  max_bounces >= 0: an invocation at depth > max_bounces returns
+        * 0 without drawing (the reference has no bound); records for up to 16 + 960 levels, beyond which the call fails
+        * with RTM_ERR_UNSUPPORTED like a PathTracing render does. */
+       RTM_MODE_SURFACE_SAMPLE = 0x400 };
 
 typedef struct rtm_options {
     int32_t mode;         /* RTM_MODE_*                                                        */
@@ -268,6 +276,14 @@ int rtm_render_objects(const rtm_settings* settings, const rtm_object* objects, 
 int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options,
                          const double* org, const double* dir, size_t n_rays,
                          double* out_radiance, uint32_t* out_draws, uint32_t* out_casts);
+
+/* ---- per-ray seam of the reference's second integrator: png::SurfaeSample (src/Renderer.cpp:119-198, entered at depth 0)
+ * for a batch of rays on device, like rtm_path_trace_batch: ray i uses the RNG stream keyed (seed, pixel = i, sample = 0);
+ * host buffers; out_draws = generator calls, out_casts = nearest-hit loops.  options->max_bounces >= 0 bounds the recursion
+ * (RTM_MODE_SURFACE_SAMPLE above); unbounded, a recursion deeper than 1 024 levels fails with RTM_ERR_UNSUPPORTED. */
+int rtm_surface_sample_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options,
+                             const double* org, const double* dir, size_t n_rays,
+                             double* out_radiance, uint32_t* out_draws, uint32_t* out_casts);
 
 /* ---- per-call seam: SphereObject::Intersect (src/SettingData.cpp:197-226) on device.
  * Pair i tests ray i against sphere i.  Host buffers.  out_t/out_normal are left untouched

@@ -128,6 +128,7 @@ typedef struct pt_env {
     int max_bounces;
     rtmo_counters* c;
     const rtm_object* objects; /* NULL: all spheres.  Else parallel to `spheres`: type and plane data */
+    int integrator;            /* 0: png::PathTracing, 1: png::SurfaeSample (RTM_MODE_SURFACE_SAMPLE) */
 } pt_env;
 
 /* png::PlaneObject — constructor src/SettingData.cpp:235-242 restated; Intersect COMPLETED by this build
@@ -260,10 +261,97 @@ static v3 path_trace(const pt_env* env, v3 org, v3 dir, rtmo_rng_fn rng, void* r
     return v3_make(0, 0, 0); /* :116 */
 }
 
+/* SphereObject::ComputeSurfacePoint src/SettingData.cpp:227-233 (a CONSTANT point: theta and phi are literals and the
+ * generator is not used) and PlaneObject::ComputeSurfacePoint :247-249 (the origin). */
+static v3 compute_surface_point(const pt_env* env, size_t i) {
+    if (env->objects && env->objects[i].type == RTM_OBJECT_PLANE) return v3_make(0, 0, 0); /* :248 */
+    const double pi = 3.14159265358979323846; /* std::numbers::pi */
+    const double theta = 2.0 * pi, phi = 0.5 * pi;                                        /* :229-230 */
+    const v3 local = v3_make(sin(theta) * sin(phi), sin(theta) * cos(phi), cos(theta));   /* :231 */
+    return v3_add(v3_scale(local, (double)env->spheres[i].radius), v3_from(env->spheres[i].center)); /* :232 */
+}
+
+/* the nearest-hit loop the reference writes out three times (src/Renderer.cpp:62-72, :126-137, :163-174) */
+static int nearest_object(const pt_env* env, v3 org, v3 dir, double* out_dis, v3* out_normal) {
+    int hit_object = -1;
+    double dis = DBL_MAX;
+    v3 normal = v3_make(0, 0, 0);
+    if (env->c) env->c->casts++;
+    for (size_t i = 0; i < env->n; ++i) {
+        double tmp_dis = 0.0;
+        v3 tmp_normal = v3_make(0, 0, 0);
+        int tmp_hit;
+        if (env->objects && env->objects[i].type == RTM_OBJECT_PLANE)
+            tmp_hit = intersect_plane(&env->objects[i], org, dir, env->mode, &tmp_dis, &tmp_normal);
+        else
+            tmp_hit = intersect(&env->spheres[i], org, dir, env->mode, &tmp_dis, &tmp_normal, env->c);
+        if (tmp_hit && tmp_dis < dis && tmp_dis > 0) {
+            dis = tmp_dis;
+            normal = tmp_normal;
+            hit_object = (int)i;
+        }
+    }
+    *out_dis = dis;
+    *out_normal = normal;
+    return hit_object;
+}
+
+/* png::SurfaeSample, src/Renderer.cpp:119-198 — the reference's second, experimental integrator (selected at :234 only
+ * if a U[0,1) draw is >= 1.0, i.e. never; it has external linkage and takes the same injectable generator).  Literal
+ * restatement, recursive like the reference.  max_bounces >= 0 is the same build extension as PathTracing's: an
+ * invocation at depth > max_bounces returns (0,0,0) without drawing (the reference has no bound; the recursion ends
+ * by its visibility, orientation and roulette tests).  Counters: casts = nearest-hit loops, bounces = invocations at
+ * depth > 0 that recursed, draws = generator calls. */
+static v3 surface_sample(const pt_env* env, v3 org, v3 dir, int depth, rtmo_rng_fn rng, void* rng_ctx) {
+    rtmo_counters* c = env->c;
+    if (c && (uint64_t)depth > c->max_depth) c->max_depth = (uint64_t)depth;
+    if (depth <= 0) { /* :120-146 */
+        double dis;
+        v3 normal;
+        const int hit = nearest_object(env, org, dir, &dis, &normal);
+        if (hit == -1) return v3_make(0, 0, 0); /* :138-140 */
+        const v3 hitpoint = v3_add(org, v3_scale(dir, dis)); /* :133 */
+        const rtm_sphere* obj = &env->spheres[hit];
+        const v3 cal = surface_sample(env, hitpoint, normal, depth + 1, rng, rng_ctx); /* :146 */
+        return v3_add(v3_mul(cal, v3_from(obj->color)), v3_from(obj->emission));         /* :147 */
+    }
+    if (env->max_bounces >= 0 && depth > env->max_bounces) return v3_make(0, 0, 0); /* build extension */
+    const int object_index = (int)(draw(rng, rng_ctx, c, 0) * (double)env->n);  /* :150 */
+    const rtm_sphere* object = &env->spheres[object_index];
+    const v3 surface_point = compute_surface_point(env, (size_t)object_index);      /* :152 */
+    const v3 check_dir = normalize3(v3_sub(surface_point, org));                    /* :160 */
+    double dis;
+    v3 normal;
+    const int hit = nearest_object(env, org, check_dir, &dis, &normal);             /* :163-174 */
+    if (hit == -1 || hit != object_index) return v3_make(0, 0, 0);                  /* :175-177 */
+    const v3 hitpoint = v3_add(org, v3_scale(check_dir, dis));                      /* :171 */
+    const v3 d = normalize3(v3_sub(surface_point, org));                            /* :179 */
+    const double dot1 = dot3(dir, d);                                               /* :180 */
+    const double dot2 = dot3(v3_neg(d), normal);                                    /* :181 */
+    if (dot1 <= 0 || dot2 <= 0) return v3_make(0, 0, 0);                            /* :182-184 */
+    const double distance = magnitude3(v3_sub(org, hitpoint));                      /* :185 */
+    const double probability = (distance < 1.0) ? 1.0 : distance;                   /* :186 std::max(a, b) = (a < b) ? b : a */
+    const double div = (1.0 < distance) ? 1.0 : distance;                           /* :187 std::min(a, b) = (b < a) ? b : a */
+    const v3 emission = v3_from(object->emission);
+    if (dot1 * dot2 * (double)rtmo_kd(object) * probability < draw(rng, rng_ctx, c, 0)) return emission; /* :188-190 */
+    if (c) c->bounces++;
+    const v3 next = surface_sample(env, hitpoint, normal, depth + 1, rng, rng_ctx); /* :191 */
+    double ckd[3];
+    rtmo_color_kd(object, ckd);
+    return v3_add(v3_scale(v3_mul(next, v3_from(ckd)), div), emission);             /* :192 */
+}
+
+void rtmo_surface_sample(const rtm_sphere* spheres, size_t n, int mode, int max_bounces, const double org[3],
+                         const double dir[3], rtmo_rng_fn rng, void* rng_ctx, double out_radiance[3],
+                         rtmo_counters* counters) {
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL, 0};
+    v3_to(surface_sample(&env, v3_from(org), v3_from(dir), 0, rng, rng_ctx), out_radiance);
+}
+
 void rtmo_path_trace(const rtm_sphere* spheres, size_t n, int mode, int max_bounces,
                      const double org[3], const double dir[3], rtmo_rng_fn rng, void* rng_ctx,
                      double out_radiance[3], rtmo_counters* counters) {
-    pt_env env = {spheres, n, mode, max_bounces, counters, NULL};
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL, 0};
     v3_to(path_trace(&env, v3_from(org), v3_from(dir), rng, rng_ctx, 0, 0), out_radiance);
 }
 
@@ -368,6 +456,8 @@ static v3 sample_radiance(const rtm_settings* st, const pt_env* env, v3 cx, v3 c
     stream_init(&rs, seed_mult, pixel, sample);
     /* src/Renderer.cpp:234's selector draw (always false for U[0,1)) is omitted: Appendix D */
     if (env->c) env->c->samples++;
+    if (env->integrator) /* RTM_MODE_SURFACE_SAMPLE: the branch src/Renderer.cpp:234-236 would take */
+        return surface_sample(env, v3_from(st->camera.origin), dir, 0, stream_next, &rs);
     return path_trace(env, v3_from(st->camera.origin), dir, stream_next, &rs, 0, 0);
 }
 
@@ -377,10 +467,20 @@ void rtmo_sample_radiance(const rtm_settings* st, const rtm_sphere* spheres, siz
     v3 cx, cy, cz;
     double fovx, fovy;
     camera_basis(st, &cx, &cy, &cz, &fovx, &fovy);
-    pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters, NULL};
+    pt_env env = {spheres, n, opt->mode & 0xFF, opt->max_bounces, counters, NULL, (opt->mode & RTM_MODE_SURFACE_SAMPLE) != 0};
     v3_to(sample_radiance(st, &env, cx, cy, cz, fovx, fovy, seed_multiplier(opt->seed), x, y, sx,
                           sy, s),
           out_radiance);
+}
+
+/* png::SurfaeSample on an arbitrary ray, drawing from the build RNG stream (seed, pixel, sample) */
+void rtmo_surface_sample_stream(const rtm_sphere* spheres, size_t n, int mode, int max_bounces, const double org[3],
+                                const double dir[3], uint64_t seed, uint32_t pixel, uint32_t sample,
+                                double out_radiance[3], rtmo_counters* counters) {
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL, 1};
+    rng_stream rs;
+    stream_init(&rs, seed_multiplier(seed), pixel, sample);
+    v3_to(surface_sample(&env, v3_from(org), v3_from(dir), 0, stream_next, &rs), out_radiance);
 }
 
 /* png::PathTracing on an arbitrary ray, drawing from the build RNG stream (seed, pixel, sample) */
@@ -388,7 +488,7 @@ void rtmo_path_trace_stream(const rtm_sphere* spheres, size_t n, int mode, int m
                             const double org[3], const double dir[3], uint64_t seed,
                             uint32_t pixel, uint32_t sample, double out_radiance[3],
                             rtmo_counters* counters) {
-    pt_env env = {spheres, n, mode, max_bounces, counters, NULL};
+    pt_env env = {spheres, n, mode, max_bounces, counters, NULL, 0};
     rng_stream rs;
     stream_init(&rs, seed_multiplier(seed), pixel, sample);
     v3_to(path_trace(&env, v3_from(org), v3_from(dir), stream_next, &rs, 0, 0), out_radiance);
@@ -484,7 +584,7 @@ static int render_core(const rtm_settings* st, const rtm_sphere* spheres, const 
             {
                 rtmo_counters local;
                 memset(&local, 0, sizeof local);
-                pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, objects};
+                pt_env env = {spheres, n, opt->mode & 0xFF, opt->max_bounces, counters ? &local : NULL, objects, (opt->mode & RTM_MODE_SURFACE_SAMPLE) != 0};
 #pragma omp for
                 for (int x = 0; x < W; ++x)
                     render_pixel(st, &env, cx, cy, cz, fovx, fovy, seed_mult, x, r0 + yy,
@@ -498,7 +598,7 @@ static int render_core(const rtm_settings* st, const rtm_sphere* spheres, const 
         {
             rtmo_counters local;
             memset(&local, 0, sizeof local);
-            pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, objects};
+            pt_env env = {spheres, n, opt->mode & 0xFF, opt->max_bounces, counters ? &local : NULL, objects, (opt->mode & RTM_MODE_SURFACE_SAMPLE) != 0};
 #pragma omp for schedule(dynamic, 16)
             for (long p = 0; p < (long)rows * W; ++p) {
                 const int yy = (int)(p / W), x = (int)(p % W);
@@ -536,7 +636,7 @@ int rtmo_render_pixels(const rtm_settings* st, const rtm_sphere* spheres, size_t
     {
         rtmo_counters local;
         memset(&local, 0, sizeof local);
-        pt_env env = {spheres, n, opt->mode, opt->max_bounces, counters ? &local : NULL, NULL};
+        pt_env env = {spheres, n, opt->mode & 0xFF, opt->max_bounces, counters ? &local : NULL, NULL, (opt->mode & RTM_MODE_SURFACE_SAMPLE) != 0};
 #pragma omp for schedule(dynamic, 1)
         for (long p = 0; p < (long)n_pixels; ++p)
             render_pixel(st, &env, cx, cy, cz, fovx, fovy, seed_mult, xy[2 * p], xy[2 * p + 1], out + (size_t)p * 3);

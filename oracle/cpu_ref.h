@@ -53,6 +53,16 @@ void rtmo_path_trace(const rtm_sphere* spheres, size_t n, int mode, int max_boun
                      const double org[3], const double dir[3], rtmo_rng_fn rng, void* rng_ctx,
                      double out_radiance[3], rtmo_counters* counters);
 
+/* png::SurfaeSample, src/Renderer.cpp:119-198 with SphereObject::ComputeSurfacePoint src/SettingData.cpp:227-233 — the
+ * reference's second integrator (never selected: src/Renderer.cpp:234 asks for a U[0,1) draw >= 1.0), restated
+ * literally; depth 0 entry.  max_bounces >= 0: an invocation at depth > max_bounces returns 0 without drawing. */
+void rtmo_surface_sample(const rtm_sphere* spheres, size_t n, int mode, int max_bounces, const double org[3],
+                         const double dir[3], rtmo_rng_fn rng, void* rng_ctx, double out_radiance[3],
+                         rtmo_counters* counters);
+void rtmo_surface_sample_stream(const rtm_sphere* spheres, size_t n, int mode, int max_bounces, const double org[3],
+                                const double dir[3], uint64_t seed, uint32_t pixel, uint32_t sample,
+                                double out_radiance[3], rtmo_counters* counters);
+
 /* Same, drawing from the build RNG stream (seed, pixel, sample) — what rtm_path_trace_batch uses */
 void rtmo_path_trace_stream(const rtm_sphere* spheres, size_t n, int mode, int max_bounces,
                             const double org[3], const double dir[3], uint64_t seed,

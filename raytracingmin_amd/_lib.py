@@ -13,6 +13,7 @@ RTM_OK = 0
 MODE_LITERAL, MODE_REPAIRED = 0, 1
 MODE_HOST_TRIG = 0x100  # flag: sin/cos exactly as the host libm returns them (include/rtm.h)
 MODE_COUNT_TESTS = 0x200  # flag: count Intersect evaluations into rtm_stats.object_tests (diagnostic)
+MODE_SURFACE_SAMPLE = 0x400  # flag: the integrator is png::SurfaeSample instead of png::PathTracing
 MODES = {"literal": MODE_LITERAL, "repaired": MODE_REPAIRED, 0: 0, 1: 1}
 
 
@@ -93,6 +94,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, _P(rtm_stats)]),
     "rtm_path_trace_batch": (C.c_int, [C.c_void_p, C.c_size_t, _P(rtm_options), C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtm_surface_sample_batch": (C.c_int, [C.c_void_p, C.c_size_t, _P(rtm_options), C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_intersect_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "rtm_intersect_objects_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,

@@ -94,6 +94,10 @@ int rtm_path_trace_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_
     RTM_GUARD(rtm::path_trace_batch(spheres, n_spheres, options, org, dir, n_rays, out_radiance,
                                     out_draws, out_casts))
 }
+int rtm_surface_sample_batch(const rtm_sphere* spheres, size_t n_spheres, const rtm_options* options, const double* org,
+                             const double* dir, size_t n_rays, double* out_radiance, uint32_t* out_draws, uint32_t* out_casts) {
+    RTM_GUARD(rtm::surface_sample_batch(spheres, n_spheres, options, org, dir, n_rays, out_radiance, out_draws, out_casts))
+}
 int rtm_intersect_batch(const rtm_sphere* spheres, const double* org, const double* dir, size_t n,
                         int mode, int32_t* out_hit, double* out_t, double* out_normal) {
     RTM_GUARD(rtm::intersect_batch(spheres, org, dir, n, mode, out_hit, out_t, out_normal))

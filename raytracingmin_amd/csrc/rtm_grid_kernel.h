@@ -35,6 +35,8 @@ constexpr int kGridWavesPerSimd = RTM_GRID_WPE;  // launch bound of the grid ker
 constexpr int kGridTermDoubles = 4;
 typedef double grid_dbl2 __attribute__((ext_vector_type(2)));
 __host__ __device__ inline size_t grid_tile_term_bytes(unsigned total_samples) { return (size_t)total_samples * 64 * kGridTermDoubles * sizeof(double); }
+// ... and its "term stored" bits behind the launch's slots: 64 bits per sample of a tile
+__host__ __device__ inline size_t grid_tile_bit_bytes(unsigned total_samples) { return (size_t)total_samples * 2 * sizeof(unsigned); }
 
 // tile of block b: blocks are dealt round-robin to the 8 XCDs, each with its own L2 (RenderParams::xcd_on)
 __device__ __forceinline__ unsigned grid_tile_of_block(const RenderParams& P, unsigned b) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     const int tile_x8 = (int)(tile % (unsigned)P.tiles_x) * 8, tile_y = (int)(tile / (unsigned)P.tiles_x);
     const unsigned total_units = P.total_samples * 64u;
     double* const terms = reinterpret_cast<double*>(P.contrib) + (size_t)local_tile * P.total_samples * (64 * kGridTermDoubles);
+    unsigned* const nz_bits = P.nz_bits + (size_t)local_tile * P.total_samples * 2;  // 64 bits per sample of the tile
 
     PathCounters pc = {0, 0, 0};
     RecordStack<RecT, LDS_D> stack{rec, lane, &P};
@@ -137,10 +140,14 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
                 // :240 cal / SS / SS / S (power-of-two divisors as exact multiplications), :241 the clamp
                 const D3 cal = pow2 ? ((L * P.inv_ss) * P.inv_ss) * P.inv_s : ((L / P.dSS) / P.dSS) / P.dS;
                 const D3 add = clamp01_d3(cal);
-                grid_dbl2* t = reinterpret_cast<grid_dbl2*>(terms + (size_t)unit * kGridTermDoubles);  // unit = sample * 64 + pixel
-                const grid_dbl2 lo = {add.x, add.y}, hi = {add.z, 0.0};
-                __builtin_nontemporal_store(lo, t);  // (system-scope write-through stores, sc0 sc1 nt, were 5 % slower)
-                __builtin_nontemporal_store(hi, t + 1);
+                // x + (+-0) == x: a term of zeros is neither stored nor read back (P.nz_bits; see RenderParams)
+                if (!(add.x == 0.0 && add.y == 0.0 && add.z == 0.0)) {
+                    grid_dbl2* t = reinterpret_cast<grid_dbl2*>(terms + (size_t)unit * kGridTermDoubles);  // unit = sample * 64 + pixel
+                    const grid_dbl2 lo = {add.x, add.y}, hi = {add.z, 0.0};
+                    __builtin_nontemporal_store(lo, t);  // (system-scope write-through stores, sc0 sc1 nt, were 5 % slower)
+                    __builtin_nontemporal_store(hi, t + 1);
+                    atomicOr(nz_bits + (unit >> 5), 1u << (unit & 31u));
+                }
                 busy = take_unit();
             }
         }
@@ -181,20 +188,32 @@ __global__ __launch_bounds__(64) void grid_finalize_kernel(const RenderParams P,
     if (!valid) return;  // (its units were never traced: the rows hold nothing for it)
     constexpr int kRow = 64 * kGridTermDoubles;  // doubles per sample row
     const double* t = reinterpret_cast<const double*>(P.contrib) + (size_t)blockIdx.x * P.total_samples * kRow + lane * kGridTermDoubles;
+    // this pixel's column of the tile's "term stored" bits: word (sample, half) holds 32 pixels
+    const unsigned* bits = P.nz_bits + (size_t)blockIdx.x * P.total_samples * 2 + (lane >> 5);
+    const unsigned my_bit = 1u << (lane & 31);
     D3 acc = d3(0, 0, 0);
     unsigned s = 0;
     for (; s + 4 <= P.total_samples; s += 4) {  // four rows in flight; the additions stay in order
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = bits[(size_t)(s + k) * 2];
+        if (__builtin_amdgcn_ballot_w64(((w[0] | w[1] | w[2] | w[3]) & my_bit) != 0u) == 0) continue;  // (no pixel of the tile has a term here)
         D3 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const grid_dbl2* r = reinterpret_cast<const grid_dbl2*>(t + (size_t)(s + k) * kRow);
-            const grid_dbl2 lo = __builtin_nontemporal_load(r), hi = __builtin_nontemporal_load(r + 1);
-            v[k] = d3(lo.x, lo.y, hi.x);
+            v[k] = d3(0, 0, 0);
+            if (w[k] & my_bit) {
+                const grid_dbl2* r = reinterpret_cast<const grid_dbl2*>(t + (size_t)(s + k) * kRow);
+                const grid_dbl2 lo = __builtin_nontemporal_load(r), hi = __builtin_nontemporal_load(r + 1);
+                v[k] = d3(lo.x, lo.y, hi.x);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc = acc + v[k];
+        for (int k = 0; k < 4; ++k)
+            if (w[k] & my_bit) acc = acc + v[k];
     }
     for (; s < P.total_samples; ++s) {
+        if (!(bits[(size_t)s * 2] & my_bit)) continue;
         const double* r = t + (size_t)s * kRow;
         acc = acc + d3(r[0], r[1], r[2]);
     }

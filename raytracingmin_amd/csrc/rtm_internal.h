@@ -41,6 +41,8 @@ int render_host_objects(const rtm_settings* st, const rtm_object* objs, size_t n
 int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,
                      const double* dir, size_t n_rays, double* out, uint32_t* out_draws,
                      uint32_t* out_casts);
+int surface_sample_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org, const double* dir,
+                         size_t n_rays, double* out, uint32_t* out_draws, uint32_t* out_casts);
 int intersect_batch(const rtm_sphere* sp, const double* org, const double* dir, size_t n, int mode,
                     int32_t* out_hit, double* out_t, double* out_normal);
 int rng_batch(uint64_t seed, uint32_t pixel0, uint32_t n_pixels, uint32_t sample, uint32_t n_draws,

@@ -41,13 +41,14 @@
 #include "rtm_wavefront.h"
 #include "rtm_fp32.h"
 #include "rtm_seam_kernels.h"
+#include "rtm_surface.h"
 
 namespace rtm {
 
 // ================================================================================================
 // Host side of the device path
 // ================================================================================================
-constexpr int kModeFlags = RTM_MODE_HOST_TRIG | RTM_MODE_COUNT_TESTS;  // flags OR-ed into rtm_options.mode
+constexpr int kModeFlags = RTM_MODE_HOST_TRIG | RTM_MODE_COUNT_TESTS | RTM_MODE_SURFACE_SAMPLE;  // flags OR-ed into rtm_options.mode
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
 const char* last_error() { return g_last_error.c_str(); }
@@ -81,7 +82,14 @@ static H3 normalize(H3 a) {
 // Flatten rtm_sphere[] to the kernel layout.  kd and colorKD are hoisted: the same
 // IEEE operations the reference redoes per bounce (src/SettingData.h:11-16).
 static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& geom,
-                          std::vector<double>& mat) {
+                          std::vector<double>& mat, std::vector<double>* surf = nullptr) {
+    if (surf) {  // png::SurfaeSample's extras: the raw colour and the radius as the float it is (rtm_surface.h)
+        surf->resize((n ? n : 1) * 4);
+        for (size_t i = 0; i < n; ++i) {
+            for (int k = 0; k < 3; ++k) (*surf)[i * 4 + k] = sp[i].color[k];
+            (*surf)[i * 4 + 3] = (double)sp[i].radius;
+        }
+    }
     geom.resize(n * 4);
     mat.assign((n + 1) * 8, 0.0);
     mat[n * 8 + 0] = mat[n * 8 + 1] = mat[n * 8 + 2] = 1.0;  // identity row for path_fold_blocked
@@ -106,13 +114,17 @@ static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& g
 }
 
 __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n,
-                                     double* __restrict__ geom, double* __restrict__ mat) {
+                                     double* __restrict__ geom, double* __restrict__ mat, double* __restrict__ surf = nullptr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == n) {  // identity row for path_fold_blocked
         for (int k = 0; k < 8; ++k) mat[n * 8 + k] = (k < 3) ? 1.0 : 0.0;
         return;
     }
     if (i >= n) return;
+    if (surf) {
+        for (int k = 0; k < 3; ++k) surf[i * 4 + k] = sp[i].color[k];
+        surf[i * 4 + 3] = (double)sp[i].radius;
+    }
     const float r2 = sp[i].radius * sp[i].radius;
     geom[i * 4 + 0] = sp[i].center[0];
     geom[i * 4 + 1] = sp[i].center[1];
@@ -243,6 +255,7 @@ struct rtm_scene {
     int device = 0;
     size_t n = 0;
     rtm::DevMem geom, mat, aux, plane;  // plane: 16 doubles per object, only for scenes that hold planes
+    rtm::DevMem surf;                   // raw colour + radius per object: png::SurfaeSample's extras (rtm_surface.h)
     rtm::DevMem grid;                   // large all-sphere scenes: GridHeader + cell offsets + cell lists + big list
     size_t grid_cells = 0, grid_refs = 0, grid_big = 0;
     rtm::GridHeader grid_hdr;           // host copy (grid_for: is the camera within the pads' reach?)
@@ -281,9 +294,10 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
     return RTM_OK;
 }
 static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n,
-                            const double* plane = nullptr, const void* grid = nullptr) {
+                            const double* plane = nullptr, const void* grid = nullptr, const double* surf = nullptr) {
     SceneView v{(const double4*)geom, mat, (int)n};
     v.plane = plane;
+    v.surf = surf;
     v.grid = static_cast<const GridHeader*>(grid);
     if (aux) {
         const size_t n_pad = (n + 7) & ~(size_t)7;
@@ -580,12 +594,14 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     RTM_HIP_CHECK(hipSetDevice(device));
     sc.device = device;
     sc.n = n;
-    std::vector<double> hg, hm;
-    flatten_scene(sp, n, hg, hm);
+    std::vector<double> hg, hm, hs;
+    flatten_scene(sp, n, hg, hm, &hs);
     int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.surf.alloc_pooled(hs.size() * sizeof(double), device);
     if (rc != RTM_OK) return rc;
+    RTM_HIP_CHECK(hipMemcpy(sc.surf.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
     if (n) RTM_HIP_CHECK(hipMemcpy(sc.geom.p, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice));
     RTM_HIP_CHECK(hipMemcpy(sc.mat.p, hm.data(), hm.size() * sizeof(double), hipMemcpyHostToDevice));
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
@@ -601,8 +617,9 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
     int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
+    if (rc == RTM_OK) rc = sc.surf.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc != RTM_OK) return rc;
-    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256>>>(sp_dev, n, sc.geom.as<double>(), sc.mat.as<double>());
+    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256>>>(sp_dev, n, sc.geom.as<double>(), sc.mat.as<double>(), sc.surf.as<double>());
     RTM_HIP_CHECK(hipGetLastError());
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
     if (rc != RTM_OK) return rc;
@@ -973,13 +990,17 @@ static const char* kVariantNames[] = {"auto", "ref-math-global-scene", "fast-mat
                                        "forward throughput: NOT a parity path, reported with its out-of-tolerance pixel fraction)"),
                                       ("fast-math-uniform-grid (large scenes held by an rtm_scene: the reference loop's nearest hit "
                                        "through a uniform grid over the spheres, same image bit for bit)"),
-                                      ("LABELLED-fp64-tolerance (the default kernel compiled with FMA contraction and one-ulp division / "
-                                       "square root, float islands, RNG, thresholds and addition order kept: within north_star's 1e-4 per "
-                                       "pixel, NOT bit-exact by construction; reported with its differing-pixel count)")};
+                                      ("fp64-tolerance (the default kernel's source compiled with FMA contraction and one-ulp division / "
+                                       "square root; float islands, RNG, thresholds, fold and addition order kept, primary-ray ties settled "
+                                       "in the reference's arithmetic: within north_star's 1e-4 per pixel by test, not bit-exact by "
+                                       "construction; reported with its differing-pixel count)"),
+                                      ("surface-sample-integrator (png::SurfaeSample, the reference's second integrator — never selected by "
+                                       "its Render —, through a general per-object kernel with the compiler's math; chosen by "
+                                       "RTM_MODE_SURFACE_SAMPLE, not by number)")};
 #undef RTM_RETIRED
 constexpr int kVariantAuto = 0, kVariantRef = 1, kVariantFastLds = 2, kVariantFastGlobal = 3, kVariantStamped = 7,
               kVariantSplit = 9, kVariantWavefrontRejectF32 = 12, kVariantGlobalDefer = 14, kVariantPrimaryReuse = 15,
-              kVariantFp32 = 16, kVariantGrid = 17, kVariantTol = 18;
+              kVariantFp32 = 16, kVariantGrid = 17, kVariantTol = 18, kVariantSurface = 19;
 static bool variant_retired(int v) { return v == 4 || v == 5 || v == 6 || v == 8 || v == 10 || v == 11 || v == 13; }
 constexpr int kLdsTableMaxSpheres = 256;  // 96 B per sphere of LDS: 24 KiB at the cap
 constexpr int kAutoLdsTableSpheres = 24, kAutoWavefrontSpheres = 512;
@@ -1711,6 +1732,7 @@ static void launch_grid_kernel(const RenderParams& P, unsigned base, unsigned cn
 // The resolved kernel variant, the sample split and stealing plans, and the bytes of every per-(device, stream) work buffer
 // the call will ask for (0 = none).  render_view acquires exactly these (and falls back where the plan says a buffer is
 // optional); rtm_scratch_bytes reports them without touching the device's memory.
+static SurfaceConsts surface_consts();
 struct RenderPlan {
     int variant = 0;          // resolved
     bool tol = false;         // the labelled tolerance row (launched from rtm_kernels_tol.hip, planned like variant 2)
@@ -1771,6 +1793,27 @@ static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, 
     if (variant < 0 || variant >= num_variants() || variant_retired(variant)) {
         set_last_error(variant >= 0 && variant < num_variants() ? std::string("variant ") + std::to_string(variant) + ": " + kVariantNames[variant]
                                                                 : std::string("no such variant"));
+        return RTM_ERR_UNSUPPORTED;
+    }
+    if (opt->mode & RTM_MODE_SURFACE_SAMPLE) {
+        // the integrator switch: png::SurfaeSample through its own general kernel (rtm_surface.h), whatever the scene's size
+        if (variant != kVariantAuto && variant != kVariantSurface) {
+            set_last_error("RTM_MODE_SURFACE_SAMPLE is served by its own kernel: variant 0 (or 19)");
+            return RTM_ERR_UNSUPPORTED;
+        }
+        if (view.surf == nullptr || n == 0) {
+            set_last_error("RTM_MODE_SURFACE_SAMPLE needs a scene with at least one object");
+            return RTM_ERR_UNSUPPORTED;
+        }
+        if (needs_pool(P)) {
+            P.pool_slots = 65536u;
+            plan.bytes[kScratchPool] = (size_t)P.pool_slots * kPoolLevels * sizeof(uint2) + 64;
+        }
+        plan.variant = kVariantSurface;
+        return RTM_OK;
+    }
+    if (variant == kVariantSurface) {
+        set_last_error("variant 19 is chosen by RTM_MODE_SURFACE_SAMPLE in rtm_options.mode");
         return RTM_ERR_UNSUPPORTED;
     }
     if (variant == kVariantAuto)
@@ -1888,7 +1931,7 @@ static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, 
         plan.bytes[kScratchWavefront] = wavefront_bytes(npix, plan.wf_levels);
     }
     if (variant == kVariantGrid) {
-        const size_t per_tile = grid_tile_term_bytes(P.total_samples);
+        const size_t per_tile = grid_tile_term_bytes(P.total_samples) + grid_tile_bit_bytes(P.total_samples);
         plan.grid_chunk_tiles = std::min<size_t>(grid, std::max<size_t>(1, grid_term_budget() / per_tile));
         plan.bytes[kScratchTerms] = plan.grid_chunk_tiles * per_tile;
         plan.optional[kScratchTerms] = true;  // what the device will not give is made up for by more launches of fewer tiles
@@ -1906,7 +1949,7 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const Rende
         const char* e = std::getenv("RTM_DEBUG_GRID_XCD");  // tuning knob: 0 = blocks render tiles in launch order
         return e && e[0] == '0';
     }();
-    const size_t per_tile = grid_tile_term_bytes(P.total_samples);
+    const size_t per_tile = grid_tile_term_bytes(P.total_samples) + grid_tile_bit_bytes(P.total_samples);
     size_t chunk = plan.grid_chunk_tiles;
     void* ws = nullptr;
     // What the device can give, asked once (a failed multi-GB hipMalloc after the old buffer has been freed costs a stream
@@ -1930,6 +1973,7 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const Rende
         chunk = (chunk + 1) / 2;
     }
     P.contrib = static_cast<unsigned char*>(ws);
+    P.nz_bits = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + chunk * grid_tile_term_bytes(P.total_samples));
     const bool deep = needs_pool(P);
     const bool planes = P.scene.plane != nullptr;
     const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
@@ -1939,6 +1983,7 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const Rende
         P.xcd_on = xcd_off ? 0u : 1u;
         P.xcd_q = cnt / 8u;
         P.xcd_rem = cnt % 8u;
+        RTM_HIP_CHECK(hipMemsetAsync(P.nz_bits, 0, (size_t)cnt * grid_tile_bit_bytes(P.total_samples), ctx.stream));
         launch_grid_kernel(P, base, cnt, lds, deep, planes, plan.count_tests, ctx.stream);
         grid_finalize_kernel<<<cnt, 64, 0, ctx.stream>>>(P, base);
     }
@@ -2022,7 +2067,7 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     if (plan.bytes[kScratchPool] != 0) {
         unsigned char* pool = nullptr;
         if (plan.packl) P.pool_slots = (P.split_first + P.n_tiles * P.split) * 128u;  // (after a possible unsplit fallback)
-        const size_t rec_bytes = (variant == kVariantGrid || n > 256) ? 4 : 1;
+        const size_t rec_bytes = variant == kVariantSurface ? sizeof(uint2) : (variant == kVariantGrid || n > 256) ? 4 : 1;
         const size_t pool_bytes = (size_t)P.pool_slots * kPoolLevels * rec_bytes;
         rc = scratch_acquire(ctx, kScratchPool, pool_bytes + 64, (void**)&pool);
         if (rc != RTM_OK) return rc;
@@ -2054,6 +2099,8 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     } else if (tol) {
         rc = launch_tol(&P, sizeof P, grid, debug_lds_pad(), stream);
         if (rc != RTM_OK) return rc;
+    } else if (variant == kVariantSurface) {
+        render_surface_kernel<<<grid, 64, (size_t)kSurfLdsLevels * 64 * sizeof(uint2), stream>>>(P, surface_consts());
     } else {
         launch_render(variant, P, grid, stream);
     }
@@ -2122,7 +2169,7 @@ int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_opti
     RenderParams P;
     RenderPlan plan;
     const SceneView view = scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt));
+                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>());
     for (int k = 0; k < 5; ++k) out[k] = 0;
     if (output_rows(opt) == 0) return RTM_OK;
     rc = plan_render(st, view, scene->n, opt, P, plan);
@@ -2151,7 +2198,7 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
     std::shared_lock<std::shared_mutex> gate(g_gate);
     reap_scenes(false);
     rc = render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt)),
+                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>()),
                      scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
     note_scene_use(scene, (hipStream_t)stream_v);  // also after a failure: part of the work may have been queued
     return rc;
@@ -2169,7 +2216,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_scene(sp, n, opt->device, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt)),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>()),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
         return rc;
@@ -2183,7 +2230,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_device_scene(sp, n, opt->device, stream, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt)),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>()),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);
         return rc;
@@ -2191,17 +2238,18 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
     // smaller device-resident arrays: flattened on the stream into stream-ordered temporaries, which are
     // released (hipFreeAsync) behind the render's launches
     keep_stream_ordered_memory(opt->device);
-    AsyncMem geom, mat, aux;
+    AsyncMem geom, mat, aux, surf;
     rc = geom.alloc((n ? n : 1) * 4 * sizeof(double), stream);
     if (rc == RTM_OK) rc = mat.alloc((n + 1) * 8 * sizeof(double), stream);
     if (rc == RTM_OK) rc = aux.alloc(scene_aux_doubles(n) * sizeof(double), stream);
+    if (rc == RTM_OK) rc = surf.alloc((n ? n : 1) * 4 * sizeof(double), stream);
     if (rc != RTM_OK) return rc;
-    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, stream>>>(sp, n, geom.as<double>(), mat.as<double>());
+    flatten_scene_kernel<<<(unsigned)((n + 1 + 255) / 256), 256, 0, stream>>>(sp, n, geom.as<double>(), mat.as<double>(), surf.as<double>());
     RTM_HIP_CHECK(hipGetLastError());
     rc = launch_scene_aux(geom.as<double>(), n, aux.as<double>(), stream);
     if (rc != RTM_OK) return rc;
-    return render_view(st, scene_view(geom.as<double>(), mat.as<double>(), aux.as<double>(), n), n, opt, out64, out32, out8,
-                       stream, stats);
+    return render_view(st, scene_view(geom.as<double>(), mat.as<double>(), aux.as<double>(), n, nullptr, nullptr, surf.as<double>()), n, opt,
+                       out64, out32, out8, stream, stats);
 }
 
 int render_host(const rtm_settings* st, const rtm_sphere* sp, size_t n, const rtm_options* opt,
@@ -2254,6 +2302,71 @@ int render_host_objects(const rtm_settings* st, const rtm_object* objs, size_t n
     }
     if (stats) *stats = local;
     return rc;
+}
+
+// SphereObject::ComputeSurfacePoint's localPoint (src/SettingData.cpp:229-231) as the HOST's libm evaluates it at run time
+// (the oracle does the same): sin(2 pi) sin(pi / 2), sin(2 pi) cos(pi / 2), cos(2 pi).
+static SurfaceConsts surface_consts() {
+    static const SurfaceConsts k = [] {
+        volatile double pi = 3.14159265358979323846;  // (volatile: evaluated by libm, not folded by the compiler)
+        const double theta = 2.0 * pi, phi = 0.5 * pi;
+        return SurfaceConsts{std::sin(theta) * std::sin(phi), std::sin(theta) * std::cos(phi), std::cos(theta)};
+    }();
+    return k;
+}
+
+// rtm_surface_sample_batch: png::SurfaeSample (depth 0 entry) for a batch of rays; ray i draws from stream (seed, i, 0)
+int surface_sample_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org, const double* dir,
+                         size_t n_rays, double* out, uint32_t* out_draws, uint32_t* out_casts) {
+    if (!opt || !sp || !n || !org || !dir || !out) {
+        set_last_error("null argument or empty scene");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if ((opt->mode & ~kModeFlags) != RTM_MODE_LITERAL && (opt->mode & ~kModeFlags) != RTM_MODE_REPAIRED) {
+        set_last_error("unknown mode");
+        return RTM_ERR_INVALID_ARGUMENT;
+    }
+    if (n_rays == 0) return RTM_OK;
+    rtm_scene ds;
+    int rc = scene_build_host(ds, sp, n, opt->device, false);
+    if (rc != RTM_OK) return rc;
+    DevMem d_org, d_dir, d_out, d_draws, d_casts, d_scratch, d_counters;
+    const size_t vb = n_rays * 3 * sizeof(double);
+    if ((rc = d_org.alloc(vb)) != RTM_OK || (rc = d_dir.alloc(vb)) != RTM_OK || (rc = d_out.alloc(vb)) != RTM_OK ||
+        (rc = d_draws.alloc(n_rays * 4)) != RTM_OK || (rc = d_casts.alloc(n_rays * 4)) != RTM_OK ||
+        (rc = d_scratch.alloc((size_t)SURF_MAX_DEPTH * n_rays * sizeof(uint2))) != RTM_OK || (rc = d_counters.alloc(32)) != RTM_OK)
+        return rc;
+    RTM_HIP_CHECK(hipMemset(d_counters.p, 0, 32));
+    RTM_HIP_CHECK(hipMemcpy(d_org.p, org, vb, hipMemcpyHostToDevice));
+    RTM_HIP_CHECK(hipMemcpy(d_dir.p, dir, vb, hipMemcpyHostToDevice));
+    SurfBatchParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = scene_view(ds.geom.as<double>(), ds.mat.as<double>(), nullptr, n, nullptr, nullptr, ds.surf.as<double>());
+    P.K = surface_consts();
+    P.mode = opt->mode & ~kModeFlags;
+    P.max_bounces = opt->max_bounces;
+    P.seed_mult = seed_multiplier(opt->seed);
+    P.org = d_org.as<double>();
+    P.dir = d_dir.as<double>();
+    P.n_rays = n_rays;
+    P.out = d_out.as<double>();
+    P.out_draws = d_draws.as<uint32_t>();
+    P.out_casts = d_casts.as<uint32_t>();
+    P.scratch = d_scratch.as<uint2>();
+    P.counters = d_counters.as<unsigned long long>();
+    surface_sample_rays_kernel<<<(unsigned)((n_rays + 63) / 64), 64>>>(P);
+    RTM_HIP_CHECK(hipGetLastError());
+    RTM_HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long c[4];
+    RTM_HIP_CHECK(hipMemcpy(c, d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    RTM_HIP_CHECK(hipMemcpy(out, d_out.p, vb, hipMemcpyDeviceToHost));
+    if (out_draws) RTM_HIP_CHECK(hipMemcpy(out_draws, d_draws.p, n_rays * 4, hipMemcpyDeviceToHost));
+    if (out_casts) RTM_HIP_CHECK(hipMemcpy(out_casts, d_casts.p, n_rays * 4, hipMemcpyDeviceToHost));
+    if (c[3]) {
+        set_last_error("a SurfaeSample recursion ran deeper than SURF_MAX_DEPTH");
+        return RTM_ERR_UNSUPPORTED;
+    }
+    return RTM_OK;
 }
 
 int path_trace_batch(const rtm_sphere* sp, size_t n, const rtm_options* opt, const double* org,

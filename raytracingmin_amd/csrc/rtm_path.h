@@ -477,6 +477,9 @@ struct SceneView {
     const double* __restrict__ plane = nullptr;
     // large all-sphere scenes held by an rtm_scene: the uniform grid of the grid kernel (variant 17), else null
     const GridHeader* __restrict__ grid = nullptr;
+    // png::SurfaeSample (rtm_surface.h) reads what PathTracing does not: per object the RAW material colour (3 doubles) and
+    // the radius as the float it is, widened (SphereObject::ComputeSurfacePoint); null where the tables were made without
+    const double* __restrict__ surf = nullptr;
 };
 
 // png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line

@@ -21,13 +21,18 @@ from .settings import SettingData
 
 class Renderer:
     def __init__(self, data: SettingData, mode="repaired", max_bounces=-1, seed=0x5EED, device=0,
-                 variant=0, host_trig=True, count_tests=False):
+                 variant=0, host_trig=True, count_tests=False, integrator="PathTracing"):
         # host_trig (default): sin/cos of src/Renderer.cpp:93-94 as the HOST's libm returns them, so a
         # render agrees with a CPU run of the reference bit for bit even on scenes that amplify one-ulp
         # differences over many bounces; host_trig=False is the labelled ~2 % faster device-trig row
         self.data = data  # the reference keeps a reference to the caller's SettingData
         # count_tests: rtm_stats.object_tests also for the uniform-grid kernel (its counting instantiation, RTM_MODE_COUNT_TESTS)
-        self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0) | (_lib.MODE_COUNT_TESTS if count_tests else 0)
+        # integrator: "PathTracing" (what the reference's Render always takes, src/Renderer.cpp:238) or "SurfaeSample" (the
+        # branch of :234-236 it never takes; RTM_MODE_SURFACE_SAMPLE, served by a general per-object kernel)
+        if integrator not in ("PathTracing", "SurfaeSample"):
+            raise ValueError(f"unknown integrator {integrator!r}")
+        self.mode = _lib.MODES[mode] | (_lib.MODE_HOST_TRIG if host_trig else 0) | (_lib.MODE_COUNT_TESTS if count_tests else 0) \
+            | (_lib.MODE_SURFACE_SAMPLE if integrator == "SurfaeSample" else 0)
         self.max_bounces = int(max_bounces)
         self.seed = int(seed)
         self.device = int(device)
@@ -185,6 +190,24 @@ def path_tracing_batch(data: SettingData, org, direction, mode="repaired", max_b
                                                direction.ctypes.data, n_rays, out.ctypes.data,
                                                draws.ctypes.data, casts.ctypes.data),
                "rtm_path_trace_batch")
+    return out, draws, casts
+
+
+def surface_sample_batch(data: SettingData, org, direction, mode="repaired", max_bounces=-1, seed=0x5EED, device=0):
+    """png::SurfaeSample (src/Renderer.cpp:119-198), entered at depth 0, for n rays; ray i draws from stream (seed, i, 0)."""
+    org = np.ascontiguousarray(org, dtype=np.float64).reshape(-1, 3)
+    direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+    n_rays = org.shape[0]
+    out = np.zeros((n_rays, 3), dtype=np.float64)
+    draws = np.zeros(n_rays, dtype=np.uint32)
+    casts = np.zeros(n_rays, dtype=np.uint32)
+    _, arr, n = data.to_c()
+    o = rtm_options()
+    o.mode = _lib.MODES[mode]
+    o.max_bounces, o.seed, o.device = int(max_bounces), int(seed), device
+    _lib.check(_lib.lib().rtm_surface_sample_batch(arr, n, C.byref(o), org.ctypes.data, direction.ctypes.data, n_rays,
+                                                   out.ctypes.data, draws.ctypes.data, casts.ctypes.data),
+               "rtm_surface_sample_batch")
     return out, draws, casts
 
 

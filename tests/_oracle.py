@@ -82,6 +82,12 @@ def lib():
         L.rtmo_path_trace_stream.argtypes = [C.POINTER(Sphere), C.c_size_t, C.c_int, C.c_int, _D3,
                                              _D3, C.c_uint64, C.c_uint32, C.c_uint32, _D3,
                                              C.POINTER(Counters)]
+        L.rtmo_surface_sample_stream.restype = None
+        L.rtmo_surface_sample_stream.argtypes = [C.POINTER(Sphere), C.c_size_t, C.c_int, C.c_int, _D3, _D3, C.c_uint64,
+                                                 C.c_uint32, C.c_uint32, _D3, C.POINTER(Counters)]
+        L.rtmo_surface_sample.restype = None
+        L.rtmo_surface_sample.argtypes = [C.POINTER(Sphere), C.c_size_t, C.c_int, C.c_int, _D3, _D3, RNG_FN, C.c_void_p, _D3,
+                                          C.POINTER(Counters)]
         L.rtmo_render.restype = C.c_int
         L.rtmo_render.argtypes = [C.POINTER(Settings), C.POINTER(Sphere), C.c_size_t,
                                   C.POINTER(Options), C.c_void_p, C.POINTER(Counters), C.c_int,
@@ -231,6 +237,27 @@ def path_trace_stream(spheres, n, mode, max_bounces, org, direction, seed, pixel
     cnt = Counters()
     lib().rtmo_path_trace_stream(spheres, n, mode, max_bounces, _D3(*org), _D3(*direction), seed,
                                  pixel, sample, out, C.byref(cnt))
+    return [out[0], out[1], out[2]], cnt.as_dict()
+
+
+MODE_SURFACE_SAMPLE = 0x400  # include/rtm.h: the integrator is png::SurfaeSample
+
+
+def surface_sample_stream(spheres, n, mode, max_bounces, org, direction, seed, pixel, sample=0):
+    """png::SurfaeSample (src/Renderer.cpp:119-198) entered at depth 0, drawing from the build RNG stream."""
+    out = _D3()
+    cnt = Counters()
+    lib().rtmo_surface_sample_stream(spheres, n, mode, max_bounces, _D3(*org), _D3(*direction), C.c_uint64(seed),
+                                     C.c_uint32(pixel), C.c_uint32(sample), out, C.byref(cnt))
+    return [out[0], out[1], out[2]], cnt.as_dict()
+
+
+def surface_sample(spheres, n, mode, max_bounces, org, direction, rng):
+    """The same with a python callable as the generator; returns (radiance[3], counters)."""
+    cb = RNG_FN(lambda _ctx: float(rng()))
+    out = _D3()
+    cnt = Counters()
+    lib().rtmo_surface_sample(spheres, n, mode, max_bounces, _D3(*org), _D3(*direction), cb, None, out, C.byref(cnt))
     return [out[0], out[1], out[2]], cnt.as_dict()
 
 

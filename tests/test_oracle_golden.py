@@ -191,3 +191,109 @@ def test_oracle_reproduces_frozen_fixtures(oracle, which):
     assert sorted(frozen.files) == sorted(now)
     for k in frozen.files:
         assert _same(frozen[k], now[k]), k
+
+
+# ---- png::SurfaeSample (src/Renderer.cpp:119-198): the oracle's restatement against a second, independent one ----------
+def _surfae_sample_py(spheres, n, org, dirn, depth, rng, stats):
+    """src/Renderer.cpp:119-198 + src/SettingData.cpp:197-233 once more, in plain Python floats (IEEE doubles), written from
+    the reference's text independently of oracle/cpu_ref.c (L1 semantics: the normal is delivered).  The reference holds
+    no fixture for this function (it never runs: :234 selects it for a U[0,1) draw >= 1.0), so two restatements check
+    each other, draws and casts included."""
+    import math
+    f32 = lambda v: float(np.float32(v))
+
+    def sub(a, b): return [a[0] - b[0], a[1] - b[1], a[2] - b[2]]
+    def add(a, b): return [a[0] + b[0], a[1] + b[1], a[2] + b[2]]
+    def scale(a, s): return [a[0] * s, a[1] * s, a[2] * s]
+    def mul(a, b): return [a[0] * b[0], a[1] * b[1], a[2] * b[2]]
+    def dot(a, b): return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+    def magnitude(a): return float(np.sqrt(np.float32(a[0] * a[0] + a[1] * a[1] + a[2] * a[2])))  # std::sqrtf
+    def normalize(a):
+        m = magnitude(a)
+        with np.errstate(all="ignore"):
+            return [float(np.float64(a[0]) / m), float(np.float64(a[1]) / m), float(np.float64(a[2]) / m)]
+
+    def intersect(s, o, d):
+        p_o = sub(list(s.center), o)
+        b = dot(p_o, d)
+        D4 = b * b - dot(p_o, p_o) + f32(np.float32(s.radius) * np.float32(s.radius))
+        if D4 < 0.0:
+            return None
+        sq = math.sqrt(D4)
+        t1, t2 = b - sq, b + sq
+        mv = f32(1e-5)
+        if t1 < mv and t2 < mv:
+            return None
+        t = t1 if t1 > 0.001 else t2
+        return t, normalize(sub(add(o, scale(d, t)), list(s.center)))
+
+    def nearest(o, d):
+        stats["casts"] += 1
+        best, dis, nrm = -1, float("inf"), [0.0, 0.0, 0.0]
+        for i in range(n):
+            r = intersect(spheres[i], o, d)
+            if r is not None and r[0] < dis and r[0] > 0:
+                best, dis, nrm = i, r[0], r[1]
+        return best, dis, nrm
+
+    def kd(s): return f32(max(s.color[0], s.color[1], s.color[2]))
+    if depth <= 0:
+        hit, dis, nrm = nearest(org, dirn)
+        if hit == -1:
+            return [0.0, 0.0, 0.0]
+        hp = add(org, scale(dirn, dis))
+        cal = _surfae_sample_py(spheres, n, hp, nrm, depth + 1, rng, stats)
+        return add(mul(cal, list(spheres[hit].color)), list(spheres[hit].emission))
+    stats["draws"] += 1
+    oi = int(rng() * n)
+    ob = spheres[oi]
+    theta, phi = 2.0 * math.pi, 0.5 * math.pi
+    local = [math.sin(theta) * math.sin(phi), math.sin(theta) * math.cos(phi), math.cos(theta)]
+    sp = add(scale(local, float(ob.radius)), list(ob.center))
+    cdir = normalize(sub(sp, org))
+    hit, dis, nrm = nearest(org, cdir)
+    if hit == -1 or hit != oi:
+        return [0.0, 0.0, 0.0]
+    hp = add(org, scale(cdir, dis))
+    d = normalize(sub(sp, org))
+    dot1, dot2 = dot(dirn, d), dot([-d[0], -d[1], -d[2]], nrm)
+    if dot1 <= 0 or dot2 <= 0:
+        return [0.0, 0.0, 0.0]
+    dist = magnitude(sub(org, hp))
+    prob, div = max(dist, 1.0), min(dist, 1.0)
+    stats["draws"] += 1
+    if dot1 * dot2 * kd(ob) * prob < rng():
+        return list(ob.emission)
+    nxt = _surfae_sample_py(spheres, n, hp, nrm, depth + 1, rng, stats)
+    k = kd(ob)
+    ckd = [ob.color[0] / k, ob.color[1] / k, ob.color[2] / k]
+    return add(scale(mul(nxt, ckd), div), list(ob.emission))
+
+
+@pytest.mark.parametrize("scene", ["cornellBoxSetting.json", "simpleSetting1.json", "simpleSetting2.json", "settingData.json"])
+def test_surfae_sample_restatement_agrees_with_an_independent_one(oracle, scene):
+    st, arr, n = oracle.load_scene(oracle.scene_path(scene))
+    rng = np.random.default_rng(31)
+    deepest = 0
+    nonzero = 0
+    for i in range(400):
+        org = [st.camera.origin[k] + rng.uniform(-0.5, 0.5) for k in range(3)]
+        d = oracle.normalize(list(rng.normal(size=3)))
+        got, cnt = oracle.surface_sample_stream(arr, n, oracle.MODE_REPAIRED, -1, org, d, 77, i)
+        k = [0]
+
+        def gen():
+            k[0] += 1
+            return oracle.lib().rtmo_rng_u01(77, i, 0, k[0] - 1)
+        stats = {"casts": 0, "draws": 0}
+        want = _surfae_sample_py(arr, n, org, d, 0, gen, stats)
+        assert np.array_equal(np.array(got).view(np.uint64), np.array(want).view(np.uint64)), (i, got, want)
+        assert (cnt["casts"], cnt["draws"]) == (stats["casts"], stats["draws"])
+        deepest = max(deepest, cnt["max_depth"])
+        nonzero += any(got)
+    print(f"{scene}: deepest recursion {deepest}, {nonzero} of 400 rays return light")
+    assert deepest >= 1 and nonzero > 0  # the recursion is exercised, and not every ray ends in zero
+    # the depth bound (a build extension): an invocation at depth > max_bounces returns 0 without drawing
+    got0, cnt0 = oracle.surface_sample_stream(arr, n, oracle.MODE_REPAIRED, 0, [st.camera.origin[k] for k in range(3)],
+                                              oracle.normalize([0.01, 0.02, 1.0]), 77, 0)
+    assert cnt0["draws"] == 0 and cnt0["casts"] == 1
