@@ -8,8 +8,12 @@
 One "step" = one full pass of the hot path over the headline workload (BASELINE.json configs[2]):
 Cornell box (scenes/cornellBoxSetting.json, unchanged), 1920x1080, 1024 spp
 (superSamples 4 x samples 64), repaired (L1) semantics, max 8 bounces, fp64, seed 0x5EED, sin/cos as the
-host libm returns them (RTM_MODE_HOST_TRIG, bit-identical to the CPU oracle; --device-trig is the labelled
-~2 % faster row), rendered into the HBM-resident float3 accumulation buffer.  With N > 1 the image is dealt out in interleaved
+host libm returns them (RTM_MODE_HOST_TRIG; --device-trig is the labelled ~2 % faster row), rendered into the
+HBM-resident float3 accumulation buffer.  Kernel: since round 4 the fp64 TOLERANCE row (variant 18: the default kernel's
+source with FMA contraction and one-ulp division / square root; asserted within north_star's 1e-4 per pixel, observed 0
+differing pixels on every BASELINE Cornell configuration — tests/test_tolerance_gpu.py); the bit-exact
+default kernel's row is measured beside it in the same run (other_configs.headline_frame_bit_exact_kernel), and --exact
+makes it the headline.  With N > 1 the image is dealt out in interleaved
 8-row bands (band b -> rank b mod N; total work fixed => "strong"), and one RCCL gather to rank 0
 ends every step inside the timed region.  metric = Msamples/s = W*H*spp / s, whole job.
 
@@ -22,8 +26,12 @@ Extra objects on the JSON line:
                  the same workload (rank 0, N = 1 only).
   with_d2h     — the same steps with the frame copied to pinned host memory inside the timed region
                  (SURVEY.md §8d wall time: kernel + final D2H); never the headline value.
-  other_configs— BASELINE configs[1] (5 steps) and a 64-row strip of configs[4], measured in this run
-                 outside the timed region (N = 1 only).
+  other_configs— the bit-exact kernel's headline row, BASELINE configs[1], configs[4] through the grid AND through the
+                 exhaustive pipeline (whole frame), the plane scene and the labelled rows, measured in this run outside the
+                 timed region (N = 1 only); every row carries its own roofline object (roofline_of: the work model follows
+                 the kernel the library reports, never a frac above 1).
+  N > 1        — frame_matches_single_gpu, config.per_rank, gather_ms (distributed.multi_gpu_evidence): the line's own proof
+                 that N ranks rendered the right frame, all outside the timed region.
 Every field says whether it was measured in this run; numbers replayed from committed profiles carry
 "measured_in_run": false and the file they come from.
 """

@@ -5,7 +5,11 @@ S, SS, bounce cap (0 .. 200 or unlimited), mode and kernel variant; every frame 
 compared with the oracle bit for bit.  Round 3: every fourth case is a scene with png::PlaneObject entries (axis-aligned and
 tilted squares among spheres inside a room sphere; variants 0, 1, 2, 9), and a third of the cases go through the
 enqueue-only entry point (rtm_render_scene without rtm_stats: sticky status, fixed trip budget of the large-scene
-pipeline) instead of the blocking one.  Results: profiles/r1/, r2/, r3/fuzz_parity.txt."""
+pipeline) instead of the blocking one.  Round 4: plane scenes up to 1 000 objects (the grid with planes among the objects
+every ray tests: variants 0 and 17), every eleventh case through the other integrator (png::SurfaeSample,
+RTM_MODE_SURFACE_SAMPLE), and — where it serves the scene — every third eligible case through the fp64 TOLERANCE row
+(variant 18), which is judged by north_star's bar (max per-pixel |delta| <= 1e-4) and counted apart, with the number of
+frames that differ at all.  Results: profiles/r1/ .. r4/fuzz_parity.txt."""
 import os
 import sys
 
@@ -26,12 +30,13 @@ def sphere(pos, r, col):
 
 
 bad = 0
+tol_cases = tol_out = tol_differ = 0
 for case in range(cases):
     n = int(rng.choice([1, 2, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
                         513, 1000, 2500]))
     kind = case % 4
     if kind == 3:  # planes and spheres mixed, in a room
-        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 24, 25, 40, 100, 254]))
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 24, 25, 40, 100, 254, 255, 256, 400, 1000]))
         objs = []
         for k in range(n):
             col = rtm.vec3(*map(float, rng.uniform(0.2, 0.9, 3)))
@@ -75,7 +80,16 @@ for case in range(cases):
         variant = 15  # the labelled primary-hit-reuse row must give the same bits where it applies
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED
     if data.has_planes():
-        variant = int(rng.choice([0, 0, 1, 2, 9]))
+        variant = int(rng.choice([0, 0, 1, 2, 9])) if n < 256 else int(rng.choice([0, 0, 1, 17]))
+    tol = (not data.has_planes()) and 1 <= n <= 24 and 0 <= mb <= 8 and data.samples * data.superSamples ** 2 < 65536 and case % 3 == 2
+    if tol:
+        variant = 18
+    surface = case % 11 == 5 and n >= 1
+    if surface:
+        variant, tol = 0, False
+        m |= oracle.MODE_SURFACE_SAMPLE
+        if mb < 0 or mb > 40:
+            mb = 40  # (unbounded, a SurfaeSample recursion in a closed bright box can run for thousands of levels)
     only = os.environ.get("FUZZ_ONLY")  # replay ONE case (the random stream is consumed as in the full run) ...
     if only is not None and case != int(only):
         continue
@@ -103,7 +117,20 @@ for case in range(cases):
         ost = oracle.Settings.from_buffer_copy(bytes(st))
         oarr = (oracle.Sphere * max(cnt_n, 1)).from_buffer_copy(bytes(arr))
         ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=seed, height=data.height))
-    r = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=variant, host_trig=host_trig)
+    r = rtm.Renderer(data, mode=mode, max_bounces=mb, seed=seed, variant=variant, host_trig=host_trig,
+                     integrator="SurfaeSample" if surface else "PathTracing")
+    if tol:  # the tolerance row: north_star's bar, counted apart
+        out, stats = r.render_rows(0, data.height, want=("f64",))
+        tol_cases += 1
+        with np.errstate(invalid="ignore"):
+            worst = float(np.nanmax(np.abs(out["f64"] - ref))) if out["f64"].size else 0.0
+        same = np.array_equal(out["f64"], ref, equal_nan=True)
+        tol_differ += not same
+        if not (worst <= 1e-4):
+            tol_out += 1
+            print("TOLERANCE ROW OUTSIDE 1e-4: case", case, dict(n=n, w=data.width, h=data.height, S=data.samples, SS=data.superSamples,
+                                                                 max_bounces=mb, mode=mode), "max pixel delta", worst)
+        continue
     if case % 3 == 1:  # the enqueue-only entry point: no rtm_stats, the stream's sticky status afterwards
         import torch
         dev_out, _ = r.render_rows_device(0, data.height, want=("f64",), stats=False)
@@ -120,4 +147,5 @@ for case in range(cases):
         print("MISMATCH case", case, dict(n=n, kind=("closed box", "stress", "stress", "planes")[kind], w=data.width, h=data.height, S=data.samples,
                                           SS=data.superSamples, max_bounces=mb, mode=mode, variant=variant),
               "max pixel delta", float(np.nanmax(np.abs(out["f64"] - ref))))
-print("seed", seed0, "cases", cases, "host_trig", host_trig, "frames differing from the oracle:", bad)
+print("seed", seed0, "cases", cases, "host_trig", host_trig, "frames differing from the oracle:", bad,
+      "| tolerance row (variant 18):", tol_cases, "frames,", tol_out, "outside 1e-4,", tol_differ, "differing at all")

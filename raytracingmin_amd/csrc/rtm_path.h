@@ -855,6 +855,9 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 #ifndef RTM_GRID_K
 #define RTM_GRID_K 4
 #endif
+#ifndef RTM_GRID_SPILL
+#define RTM_GRID_SPILL 1
+#endif
 constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_crossover.txt)
 #ifndef RTM_GRID_SHADE_AT
 #define RTM_GRID_SHADE_AT 5
@@ -1077,6 +1080,26 @@ struct GridWalk {
             // records left issues two loads): the walk is bound by the vector memory pipeline, which pays per lane and
             // distinct line (profiles/r3/grid_perturbation.txt: the same loads issued twice cost +31 %, the tests'
             // arithmetic twice +8 %), so nothing is fetched that is not needed.
+#if RTM_GRID_SPILL
+            // (round 4, profiles/r4/grid_spill.txt: 201.0 -> 197.1 ms for the configs[4] frame; RTM_GRID_SPILL=0 is the twin)
+            // A lane whose cell has fewer than kGridBatch records left fills its free slots with the first records of the
+            // NEXT cell on its ray (their range is known already), unless the walk is known to end in this cell.  Testing
+            // a sphere early, or one the walk would never have reached, changes nothing (see above: any order, ties by
+            // index); it makes the slots fuller and the next cell shorter.
+            const unsigned left1 = jend - j < (unsigned)kGridBatch ? jend - j : (unsigned)kGridBatch;
+            const bool spill = left1 < (unsigned)kGridBatch && next_ok && !(dis <= t_exit);
+            const unsigned room = (unsigned)kGridBatch - left1, avail = nje - nj;
+            const unsigned left2 = spill ? (avail < room ? avail : room) : 0u;
+            const unsigned left = left1 + left2;
+            double4 r[kGridBatch];
+#pragma unroll
+            for (unsigned k = 0; k < (unsigned)kGridBatch; ++k)
+                if (left > k) r[k] = G->recs[k < left1 ? j + k : nj + (k - left1)];
+            nj += left2;
+#pragma unroll
+            for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
+                if (left > k) {
+#else
             const double4* recs = G->recs + j;
             const unsigned left = jend - j;
             double4 r[kGridBatch];
@@ -1086,6 +1109,7 @@ struct GridWalk {
 #pragma unroll
             for (unsigned k = 0; k < (unsigned)kGridBatch; ++k) {
                 if (left > k) {
+#endif
                     RTM_GRID_OCC(3 + k);
                     if constexpr (COUNT) ++tests;
                     // src/SettingData.cpp:198-200; the sphere's index rides in the low 29 mantissa bits of the float-valued r*r
@@ -1102,7 +1126,11 @@ struct GridWalk {
                     }
                 }
             }
+#if RTM_GRID_SPILL
+            j += left1;
+#else
             j = left > (unsigned)kGridBatch ? j + (unsigned)kGridBatch : jend;
+#endif
         }
         if (pending != 0u) {  // one candidate per lane and trip: :205-223 and the caller's acceptance (src/Renderer.cpp:67)
             RTM_GRID_OCC(7);

@@ -45,13 +45,14 @@ class Renderer:
     # ---- the scene on the device: flattened and uploaded once per renderer -------------------
     def _scene_handle(self):
         """rtm_scene_create once; made again whenever the scene may have changed since — the reference reads the live
-        SettingData at render time (src/Renderer.h:16), and so must this: the key holds the identities of the list's
-        objects in order (replaced, reordered, added, removed entries) and the edit epoch of settings.py (any field of
-        any scene object written in place).  A needless re-flatten after unrelated edits costs a re-upload that the
-        library's content-addressed scene cache makes cheap; a stale scene is never rendered."""
+        SettingData at render time (src/Renderer.h:16), and so must this.  The key is O(1) per render: the edit epoch of
+        settings.py counts every write to a scene object's fields AND every assignment or mutation of a SettingData's
+        object list (replaced, reordered, added, removed entries); camera edits do not count (the camera is not part of
+        the uploaded scene).  Edits to ANOTHER SettingData also advance the epoch: a needless re-flatten, never a stale
+        scene."""
         from .settings import edit_epoch
         objs = self.data.object
-        key = (edit_epoch(), len(objs), hash(tuple(map(id, objs))))
+        key = (edit_epoch(), id(objs))
         if self._scene is None or key != self._scene_key:
             self.invalidate()
             h = C.c_void_p()

@@ -13,22 +13,47 @@ from . import _lib
 from ._lib import rtm_object, rtm_settings, rtm_sphere
 
 
-_EDITS = [0]  # bumped by every attribute write on a scene object (construction included)
+_EDITS = [0]  # bumped by every write that can change a scene's OBJECTS (construction included)
 
 
 def edit_epoch():
-    """Changes whenever any vec3 / Material / SphereObject / PlaneObject was written to or constructed: with the
-    identities of a scene's objects it tells a Renderer that its uploaded copy may be stale (renderer.py).  The
-    reference reads the live SettingData at render time (src/Renderer.h:16); so does this mirror."""
+    """Changes whenever any vec3 / Material / SphereObject / PlaneObject was written to or constructed, or a SettingData's
+    object list was assigned or mutated: it tells a Renderer that its uploaded copy may be stale (renderer.py) in O(1)
+    per render.  The reference reads the live SettingData at render time (src/Renderer.h:16); so does this mirror.  The
+    CAMERA is not part of the uploaded scene (it travels with every call in rtm_settings): writes to a Camera's vectors do
+    not count, so moving the camera over a 100 000-sphere scene does not re-flatten and re-upload it."""
     return _EDITS[0]
 
 
 class _Tracked:
     __slots__ = ()
 
+    def __post_init__(self):  # (dataclass construction is over: from here on a write is an edit of a live object)
+        object.__setattr__(self, "_live", True)
+
     def __setattr__(self, name, value):
-        _EDITS[0] += 1
+        # a write to a live scene object counts; the writes of an object's own construction do not (a new object changes
+        # a scene only when it is attached to one: that write, or the list mutation, counts)
+        if getattr(self, "_live", False) and not getattr(self, "_quiet", False):
+            _EDITS[0] += 1
         object.__setattr__(self, name, value)
+
+
+class _TrackedList(list):
+    """SettingData.object: a list whose mutations count as scene edits (replacing, reordering, adding or removing an
+    entry changes the scene without writing to any object)."""
+    __slots__ = ()
+
+    def _bump(name):  # noqa: N805 — builds the wrappers below
+        def wrapper(self, *a, **kw):
+            _EDITS[0] += 1
+            return getattr(list, name)(self, *a, **kw)
+        wrapper.__name__ = name
+        return wrapper
+    for _n in ("append", "extend", "insert", "remove", "pop", "clear", "sort", "reverse", "__setitem__", "__delitem__",
+               "__iadd__", "__imul__"):
+        locals()[_n] = _bump(_n)
+    del _n, _bump
 
 
 @dataclass
@@ -73,6 +98,11 @@ class Camera:  # src/SettingData.h:43-46
     upVec: vec3 = field(default_factory=lambda: vec3(0, 1, 0))
     fov: float = 60.0
 
+    def __setattr__(self, name, value):
+        if isinstance(value, vec3):  # a camera's vectors are not scene objects: writes to them are not scene edits
+            object.__setattr__(value, "_quiet", True)
+        object.__setattr__(self, name, value)
+
 
 @dataclass
 class SettingData:  # src/SettingData.h:47-51
@@ -82,6 +112,12 @@ class SettingData:  # src/SettingData.h:47-51
     superSamples: int = 1
     camera: Camera = field(default_factory=Camera)
     object: List[SphereObject] = field(default_factory=list)
+
+    def __setattr__(self, name, value):
+        if name == "object":  # (a plain list handed in is copied into the tracking kind: mutate data.object, not the original)
+            _EDITS[0] += 1
+            value = value if isinstance(value, _TrackedList) else _TrackedList(value)
+        object.__setattr__(self, name, value)
 
     # ---- flattening to / from the C ABI structs
     def to_c(self):

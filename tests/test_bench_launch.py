@@ -88,3 +88,10 @@ def test_bench_gpus_2_self_launch_renders_on_the_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0
     assert j["config"]["collective"] == "gloo gather, 2 rank(s)"
     assert "timed step(s)" in r.stderr
+    # the N-rank line proves itself: the gathered frame equals rank 0's own single-launch render bit for bit, every rank's
+    # kernel time / rows / counters are in the line, the gather alone is timed
+    assert j["frame_matches_single_gpu"] is True and j["gather_ms"] > 0.0
+    per_rank = j["config"]["per_rank"]
+    assert [p["rank"] for p in per_rank] == [0, 1] and sum(p["rows"] for p in per_rank) == 144
+    assert all(p["kernel_ms"] > 0 and p["casts"] >= p["samples"] > 0 for p in per_rank)
+    assert sum(p["samples"] for p in per_rank) == 256 * 144 * 16

@@ -204,7 +204,7 @@ def test_plane_objects_in_the_oracle(oracle):
 
 def test_edit_epoch_sees_every_write_on_a_scene_object():
     """settings.edit_epoch(): what lets a Renderer notice in-place edits of the caller's SettingData (the reference
-    reads the live scene at render time); identities of the list's entries cover replacement and reordering."""
+    reads the live scene at render time); the tracking object list covers replacement and reordering."""
     import _oracle
     from raytracingmin_amd.settings import edit_epoch
     data = rtm.LoadData(_oracle.scene_path("cornellBoxSetting.json")).data
@@ -218,9 +218,10 @@ def test_edit_epoch_sees_every_write_on_a_scene_object():
     assert e0 < e1 < e2 < e3
     ids = tuple(map(id, data.object))
     data.object[1], data.object[2] = data.object[2], data.object[1]
-    assert tuple(map(id, data.object)) != ids and edit_epoch() == e3  # reordering writes nothing: the ids catch it
+    e4 = edit_epoch()
+    assert tuple(map(id, data.object)) != ids and e4 > e3  # reordering writes to no object: the tracking list counts it
     rtm.PlaneObject()
-    assert edit_epoch() > e3                                           # construction counts (conservative)
+    assert edit_epoch() == e4  # constructing an object that is attached to nothing changes no scene (round 4)
 
 
 def _grid_build(arr, n):
@@ -285,3 +286,38 @@ def test_grid_builder_lists_cover_every_padded_sphere():
     # too few gridded spheres: no grid
     few = (_lib.rtm_sphere * 40)(*arr[4:44])
     assert _grid_build(few, 40)[0] == _lib.lib().rtm_debug_grid_build(few, 40, (C.c_uint64 * 12)(), None, None, 0, None, 0, None, 0) != 0
+
+
+def test_scene_edit_epoch_counts_scene_edits_only():
+    """renderer.py re-uploads a scene when settings.edit_epoch() has advanced (O(1) per render; ADVICE r3: the key used to
+    hash every object's identity per render, and a camera move re-flattened a 100 000-sphere scene).  What counts: writes
+    to live scene objects and every assignment or mutation of a SettingData's object list.  What does not: constructing
+    objects that are not attached to anything yet, and camera edits (the camera travels with every call)."""
+    import raytracingmin_amd as rtm
+    from raytracingmin_amd.settings import edit_epoch
+    d = rtm.SettingData()
+    e = edit_epoch()
+    d.camera.origin.x = 3.0
+    d.camera.origin = rtm.vec3(1, 2, 3)
+    d.camera.origin.y = 5.0
+    d.camera.fov = 3.0
+    d.width, d.samples = 64, 4
+    s = rtm.SphereObject(rtm.vec3(1, 1, 1), 2.0, rtm.Material(rtm.vec3(.5, .5, .5), rtm.vec3()))
+    assert edit_epoch() == e
+    d.object.append(s)
+    assert edit_epoch() == e + 1
+    s.m_position.x = 2.0
+    s.m_material.emission = rtm.vec3(1, 1, 1)
+    s.m_size = 3.0
+    assert edit_epoch() == e + 4
+    for mutate in (lambda: d.object.reverse(), lambda: d.object.insert(0, rtm.SphereObject()), lambda: d.object.pop(),
+                   lambda: d.object.__setitem__(0, s), lambda: setattr(d, "object", [s, rtm.SphereObject()]),
+                   lambda: d.object.extend([rtm.SphereObject()]), lambda: d.object.sort(key=id), lambda: d.object.clear()):
+        before = edit_epoch()
+        mutate()
+        assert edit_epoch() > before
+    import _oracle
+    loaded = rtm.LoadData(_oracle.scene_path("cornellBoxSetting.json")).data
+    before = edit_epoch()
+    loaded.object.pop()
+    assert edit_epoch() > before  # the loader's list is the tracking kind too

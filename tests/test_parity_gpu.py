@@ -41,7 +41,7 @@ def _variants(rtm, data, max_bounces):
     n = len(data.object)
     live = [v for v in range(rtm.lib().rtm_num_variants()) if not rtm.lib().rtm_variant_name(v).startswith(b"retired")]
     return [v for v in live
-            if v not in (16, 17, 18) and (v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8))]  # 16: the fp32 row, not a parity path; 18: the fp64 tolerance row (tests/test_tolerance_gpu.py)
+            if v not in (16, 17, 18, 19) and (v != 15 or (1 <= n <= 24 and 0 <= max_bounces <= 8))]  # 16: the fp32 row, not a parity path; 18: the fp64 tolerance row (tests/test_tolerance_gpu.py); 19: the other integrator (tests/test_surface_gpu.py)
 
 
 def _probe(rtm, op, a, b=None):
