@@ -183,12 +183,13 @@ int rtm_release_scratch(int device);
 /* What a render with these arguments will ask of those work buffers, in bytes, before anything is allocated:
  * out_bytes[0] the total, [1] per-sample terms (sample split of a launch's last tiles / the grid kernel's term buffer:
  * one launch's worth, at most the 16 GiB budget), [2] pooled hit records (unlimited depth or a cap of 16 and more),
- * [3] the exhaustive large-scene pipeline's path state, [4] the rows of in-wave sample stealing.  The buffers are per
+ * [3] the exhaustive large-scene pipeline's path state, [4] the rows of in-wave sample stealing, [5] the table of primary
+ * directions a pre-pass leaves for the default kernels (1.5 KiB per tile and sub-pixel, at most 4 GiB).  The buffers are per
  * (device, stream), grown on demand and kept until rtm_release_scratch / rtm_stream_release; a stream that has rendered
  * larger frames already holds more.  Where the device cannot give an OPTIONAL buffer (terms, stolen rows) the render
  * runs without the feature or in more launches — same image. */
 int rtm_scratch_bytes(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options,
-                      uint64_t out_bytes[5]);
+                      uint64_t out_bytes[6]);
 /* The same for ONE stream: waits for that stream's queued work (and, like rtm_release_scratch, for every render call
  * that is being enqueued at that moment), frees the buffers and the sticky status word the
  * library keeps for (device, stream) and forgets the pair.  Call it before destroying a stream that has rendered

@@ -40,7 +40,7 @@ int rtm_num_variants(void) { return rtm::num_variants(); }
 int rtm_output_rows(const rtm_options* options) { return options ? rtm::output_rows(options) : 0; }
 int rtm_release_scratch(int device) { RTM_GUARD(rtm::release_scratch(device)) }
 int rtm_stream_release(int device, void* stream) { RTM_GUARD(rtm::stream_release(device, stream)) }
-int rtm_scratch_bytes(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options, uint64_t out_bytes[5]) {
+int rtm_scratch_bytes(const rtm_settings* settings, const rtm_scene* scene, const rtm_options* options, uint64_t out_bytes[6]) {
     RTM_GUARD(rtm::scratch_bytes(settings, scene, options, out_bytes))
 }
 const char* rtm_variant_name(int variant) { return rtm::variant_name(variant); }

@@ -28,7 +28,7 @@ int intersect_objects_batch(const rtm_object* objs, const double* org, const dou
 int scene_destroy(rtm_scene* sc);
 size_t scene_size(const rtm_scene* sc);
 int stream_status(int device, void* stream);
-int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[5]);
+int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[6]);
 int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, double* out64, float* out32,
                  uint8_t* out8, void* stream, rtm_stats* stats);
 int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int spheres_on_device,

@@ -1211,7 +1211,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
 // naming the same (device, stream) take turns and never see each other's half-grown buffers; `g_gate` is
 // held shared by every render and exclusively by release_scratch, which therefore never frees anything
 // under a call that is between acquiring a buffer and launching on it.
-enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchSteal = 3, kScratchRoles = 4 };
+enum { kScratchTerms = 0, kScratchPool = 1, kScratchWavefront = 2, kScratchSteal = 3, kScratchPrim = 4, kScratchRoles = 5 };
 namespace {
 struct ScratchBuf {
     void* ptr = nullptr;
@@ -1733,6 +1733,18 @@ static void launch_grid_kernel(const RenderParams& P, unsigned base, unsigned cn
 // the call will ask for (0 = none).  render_view acquires exactly these (and falls back where the plan says a buffer is
 // optional); rtm_scratch_bytes reports them without touching the device's memory.
 static SurfaceConsts surface_consts();
+// The deferred-fold kernels' pre-pass (rtm_render_kernel.h: prim_prepass_kernel) leaves, per tile of the launch, every
+// sub-pixel's primary direction — up to 4 GiB per launch, else the kernels compute them where they need them — and, for the
+// tolerance row, 64 mask words.
+static size_t prim_dir_bytes(unsigned tiles, int ss) {
+    static const bool off = [] {
+        const char* e = std::getenv("RTM_DEBUG_PRIM_DIRS");  // A/B knob: 0 = no direction table
+        return e && e[0] == '0';
+    }();
+    const size_t b = (size_t)tiles * (size_t)ss * (size_t)ss * 3 * 64 * sizeof(double);
+    return (off || b > ((size_t)4 << 30)) ? 0 : b;
+}
+static size_t prim_mask_bytes(unsigned tiles) { return (size_t)tiles * 64 * sizeof(unsigned long long); }
 struct RenderPlan {
     int variant = 0;          // resolved
     bool tol = false;         // the labelled tolerance row (launched from rtm_kernels_tol.hip, planned like variant 2)
@@ -1741,8 +1753,9 @@ struct RenderPlan {
     bool count_tests = false; // RTM_MODE_COUNT_TESTS
     unsigned grid = 0;        // tiles of the launch
     int rows = 0;
-    size_t bytes[kScratchRoles] = {0, 0, 0, 0};
-    bool optional[kScratchRoles] = {false, false, false, false};  // without room the launch runs without the feature
+    size_t bytes[kScratchRoles] = {0, 0, 0, 0, 0};
+    bool optional[kScratchRoles] = {false, false, false, false, false};  // without room the launch runs without the feature
+    bool prepass = false;     // the deferred-fold kernels' pre-pass table (primary directions; the tolerance row: + masks)
     // steal plan
     unsigned steal_rows = 0, steal_depth = 0;
     bool steal = false;
@@ -1913,7 +1926,13 @@ static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, 
         // to steal_finalize_kernel
         plan.bytes[kScratchSteal] = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(0);
     }
-    if (tol) plan.bytes[kScratchSteal] += (size_t)grid * 64 * sizeof(unsigned long long);  // + the primary-ray masks (prim_mask_kernel)
+    // the pre-pass table of the deferred-fold kernels: primary directions (optional), the tolerance row's masks (needed)
+    if (variant == kVariantFastLds || variant == kVariantGlobalDefer) {
+        const bool defer = n < 256;  // (launch_render: from 256 objects these variants hand over to the kernels without a fold queue)
+        plan.bytes[kScratchPrim] = (defer ? prim_dir_bytes(grid, P.SS) : 0) + (tol ? prim_mask_bytes(grid) : 0);
+        plan.prepass = plan.bytes[kScratchPrim] != 0;
+        plan.optional[kScratchPrim] = !tol;
+    }
     // deep-path record pool.  Kernels with an LDS record stack take a slot only for the
     // rare path beyond 64/32 levels (65536 slots x 960 records: 60 MiB u8 / 240 MiB u32); the packed-record
     // kernels (PACKL) keep levels >= 16 there, which nearly every pixel needs once: one slot per lane.
@@ -2041,18 +2060,16 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
         const unsigned n_whole = P.split > 1 ? P.split_first : grid;  // (an unsplit fallback has more whole tiles than planned)
         unsigned srows = plan.steal ? plan.steal_rows : 0u;
         void* ws = nullptr;
-        const size_t mask_bytes = tol ? (size_t)grid * 64 * sizeof(unsigned long long) : 0;  // behind the tiles' blocks
         size_t blocks = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(srows);
-        rc = (n_whole || tol) ? scratch_acquire(ctx, kScratchSteal, blocks + mask_bytes, &ws) : RTM_ERR_HIP;
+        rc = (n_whole || tol) ? scratch_acquire(ctx, kScratchSteal, blocks, &ws) : RTM_ERR_HIP;
         if (rc != RTM_OK && tol) {  // the tolerance row cannot run without its blocks: the smallest form, or fail
             (void)hipGetLastError();
             srows = 0;
             blocks = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(0);
-            rc = scratch_acquire(ctx, kScratchSteal, blocks + mask_bytes, &ws);
+            rc = scratch_acquire(ctx, kScratchSteal, blocks, &ws);
             if (rc != RTM_OK) return rc;
         }
         if (rc == RTM_OK) {
-            if (tol) P.prim_masks = reinterpret_cast<const unsigned long long*>(static_cast<unsigned char*>(ws) + blocks);
             P.steal_ws = static_cast<unsigned char*>(ws);
             P.steal_rows = srows;
             P.steal_depth = srows ? plan.steal_depth : 0u;
@@ -2060,6 +2077,25 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
                 P.magic_S = (unsigned)(0x100000000ull / (unsigned long long)st->samples) + 1u;
                 P.magic_SS = (unsigned)(0x100000000ull / (unsigned long long)st->super_samples) + 1u;
             }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (plan.prepass) {
+        // (an unsplit fallback keeps the grid's tile count: the table is indexed by tile of the launch)
+        void* ws = nullptr;
+        size_t dir_bytes = plan.bytes[kScratchPrim] - (tol ? prim_mask_bytes(grid) : 0);
+        rc = scratch_acquire(ctx, kScratchPrim, plan.bytes[kScratchPrim], &ws);
+        if (rc != RTM_OK && tol) {  // no room for the directions: the masks alone, or fail
+            (void)hipGetLastError();
+            dir_bytes = 0;
+            rc = scratch_acquire(ctx, kScratchPrim, prim_mask_bytes(grid), &ws);
+            if (rc != RTM_OK) return rc;
+        }
+        if (rc == RTM_OK) {
+            unsigned char* base = static_cast<unsigned char*>(ws);
+            if (tol) P.prim_masks = reinterpret_cast<const unsigned long long*>(base);
+            if (dir_bytes != 0) P.prim_dirs = reinterpret_cast<const double*>(base + (tol ? prim_mask_bytes(grid) : 0));
         } else {
             (void)hipGetLastError();
         }
@@ -2102,6 +2138,8 @@ static int render_view(const rtm_settings* st, const SceneView& view, size_t n, 
     } else if (variant == kVariantSurface) {
         render_surface_kernel<<<grid, 64, (size_t)kSurfLdsLevels * 64 * sizeof(uint2), stream>>>(P, surface_consts());
     } else {
+        if (P.prim_dirs != nullptr)  // the deferred-fold kernels' pre-pass: every sub-pixel's primary direction, once
+            prim_prepass_kernel<<<P.split > 1 ? P.split_first + P.n_tiles : grid, 64, 0, stream>>>(P, nullptr, const_cast<double*>(P.prim_dirs));
         launch_render(variant, P, grid, stream);
     }
     RTM_HIP_CHECK(hipGetLastError());
@@ -2158,8 +2196,8 @@ static const void* grid_for(const rtm_scene* sc, const rtm_settings* st, const r
 
 // rtm_scratch_bytes: what a render with these arguments asks of the per-(device, stream) work buffers (plan_render), without
 // touching the device's memory.  out[0] total, out[1] per-sample terms (sample split / grid kernel), out[2] pooled hit
-// records, out[3] the exhaustive pipeline's path state, out[4] stolen samples' rows.
-int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[5]) {
+// records, out[3] the exhaustive pipeline's path state, out[4] stolen samples' rows, out[5] the pre-pass's table.
+int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_options* opt, uint64_t out[6]) {
     if (!scene || !out) {
         set_last_error("null argument");
         return RTM_ERR_INVALID_ARGUMENT;
@@ -2170,7 +2208,7 @@ int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_opti
     RenderPlan plan;
     const SceneView view = scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
                                       scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>());
-    for (int k = 0; k < 5; ++k) out[k] = 0;
+    for (int k = 0; k < 6; ++k) out[k] = 0;
     if (output_rows(opt) == 0) return RTM_OK;
     rc = plan_render(st, view, scene->n, opt, P, plan);
     if (rc != RTM_OK) return rc;
@@ -2178,7 +2216,8 @@ int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_opti
     out[2] = plan.bytes[kScratchPool];
     out[3] = plan.bytes[kScratchWavefront];
     out[4] = plan.bytes[kScratchSteal];
-    out[0] = out[1] + out[2] + out[3] + out[4];
+    out[5] = plan.bytes[kScratchPrim];
+    out[0] = out[1] + out[2] + out[3] + out[4] + out[5];
     return RTM_OK;
 }
 

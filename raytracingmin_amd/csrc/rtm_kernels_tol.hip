@@ -7,7 +7,8 @@
 // float islands of src/Ray.h:67-72, src/SettingData.h:14-16 and src/SettingData.cpp:200,208, the same order of the
 // additions into Renderer::image) a second time, into namespace rtm_tol, with
 //   * FMA contraction allowed (-ffp-contract=fast-honor-pragmas), and
-//   * division and square root to about one ulp (RTM_TOL: rtm_path.h, seq_rcp / seq_quot / seq_sqrt);
+//   * division and square root to about one ulp (RTM_TOL: rtm_path.h, seq_rcp / seq_quot / seq_sqrt), sin / cos as the
+//     device evaluates them (within one ulp of the host libm's; RTM_MODE_HOST_TRIG has no effect on this row);
 //   * the fold L = colorKD * L + emission (src/Renderer.cpp:109) kept unfused (rtm_device.h: fold_step), so that a
 //     sample's value stays a function of its path's hit ids alone: the image differs from the exact kernel's only where
 //     a last-bit difference in a distance or a direction changes WHICH sphere a ray hits.
@@ -89,6 +90,10 @@ int launch_tol(const void* params, size_t params_bytes, unsigned grid, size_t ld
         return RTM_ERR_INVALID_ARGUMENT;
     }
     std::memcpy(&P, params, sizeof P);
+    // RTM_MODE_HOST_TRIG turns the device's sin / cos into the host libm's, one ulp apart on 3 % of the arguments: a
+    // distinction this unit's own arithmetic does not keep anywhere else.  The row takes the device's (one table gather and
+    // ten instructions per bounce less); the flag is accepted and has no effect here.
+    P.scene.trig_fix = nullptr;
     hipStream_t stream = (hipStream_t)stream_v;
     if (P.steal_ws == nullptr || P.scene.n < 1 || P.scene.n > 24 || P.scene.plane != nullptr || P.max_bounces < 0 ||
         P.max_bounces > 8 || P.total_samples >= 65536u) {
@@ -106,10 +111,12 @@ int launch_tol(const void* params, size_t params_bytes, unsigned grid, size_t ld
         const char* e = std::getenv("RTM_DEBUG_TOL_PRIMFIX");  // A/B knob: 0 = no primary ray is flagged (NOT within tolerance on the Cornell diagonals)
         return e && e[0] == '0';
     }();
+    if (no_masks) P.prim_dirs = nullptr;
     if (no_masks)
         (void)hipMemsetAsync(const_cast<unsigned long long*>(P.prim_masks), 0, (size_t)n_tiles_all * 64 * sizeof(unsigned long long), stream);
     else
-        rtm_tol::prim_mask_kernel<<<n_tiles_all, 64, 0, stream>>>(P, const_cast<unsigned long long*>(P.prim_masks));
+        rtm_tol::prim_prepass_kernel<<<n_tiles_all, 64, 0, stream>>>(P, const_cast<unsigned long long*>(P.prim_masks),
+                                                                 const_cast<double*>(P.prim_dirs));
     if (P.split > 1) {
         rtm_tol::launch_n<true>(P, P.split_first + P.n_tiles * P.split, lds_pad, stream);
         rtm_tol::split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);

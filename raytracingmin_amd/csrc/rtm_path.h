@@ -281,11 +281,17 @@ struct MathSpecT {
     // zero component (square +0) trips it too and sends the wave down the compiler's path: correct, and
     // for directions that went through a random bounce a measure-zero event.
     __device__ __forceinline__ D3 div3_by_magnitude(D3 a, double sx, double sy, double sz, float len2) {
+#if RTM_TOL
+        // (the tolerance unit's quotient is x * (1 / y): no remainder step that a tiny component could break, no guard for one)
+        (void)sx; (void)sy; (void)sz;
+        bad = bad | !sqrtf_fast_ok(len2);
+#else
         unsigned lo = (unsigned)__double2hiint(sx);
         const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
         lo = hy < lo ? hy : lo;
         lo = hz < lo ? hz : lo;
         bad = bad | !sqrtf_fast_ok(len2) | (lo < 0x0DF00000u);  // 2^-800
+#endif
         const double y = (double)sqrtf_fast(len2);
         const double r = seq_rcp(y);
         // no v_div_fixup: with a non-zero, non-tiny, finite numerator and a denominator in [2^-48, 2^64) it returns
@@ -331,8 +337,12 @@ struct MathSpecT {
     __device__ __forceinline__ void normalize_xz(double cx, double cz, double& ux, double& uz) {
         const double sx = cx * cx, sz = cz * cz;
         const float len2 = (float)(sx + sz);
+#if RTM_TOL
+        bad = bad | !sqrtf_fast_ok(len2);
+#else
         const unsigned hx = (unsigned)__double2hiint(sx), hz = (unsigned)__double2hiint(sz);
         bad = bad | !sqrtf_fast_ok(len2) | ((hx < hz ? hx : hz) < 0x0DF00000u);  // see div3_by_magnitude
+#endif
         const double y = (double)sqrtf_fast(len2);
         const double r = seq_rcp(y);
         auto one = [&](double x) {  // no v_div_fixup: see div3_by_magnitude
@@ -354,11 +364,13 @@ struct MathSpecT {
             if (__builtin_amdgcn_ballot_w64(!canon) != 0) return div3_by_magnitude(dv, sx, sy, sz, len2f);
             // canonical: |dv|^2 rounds to the float r*r of a sphere whose refined reciprocal exists (rinv is NaN when
             // ms is outside the exact range), so only a tiny component remains to be excluded
+#if !RTM_TOL
             unsigned lo = (unsigned)__double2hiint(sx);
             const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
             lo = hy < lo ? hy : lo;
             lo = hz < lo ? hz : lo;
             bad = bad | (lo < 0x0DF00000u);
+#endif
             auto one = [&](double x) {
                 return seq_quot(x, ms, rinv);  // no v_div_fixup: see div3_by_magnitude
             };
@@ -1268,7 +1280,7 @@ __device__ __forceinline__ int nearest_hit_exactfp(const Scene& sc, const D3 org
 // The loop again in the reference's arithmetic, with a margin on every decision it makes: a discriminant whose sign, a root
 // whose place against the 0.001 and 1e-5f thresholds, or a nearest hit whose lead over the runner-up is within 1e-11 of the
 // operands' magnitude — five orders above what contraction and one-ulp roots can move them by (~1e-16 of the same
-// magnitudes) — is "at risk".  prim_mask_kernel (rtm_render_kernel.h) evaluates it once per sub-pixel.
+// magnitudes) — is "at risk".  prim_prepass_kernel (rtm_render_kernel.h) evaluates it once per sub-pixel.
 template <class Scene>
 __device__ __forceinline__ bool primary_tie_risk(const Scene& sc, const D3 org, const D3 dir) {
 #pragma clang fp contract(off)

@@ -55,8 +55,13 @@ struct RenderParams {
     // contiguous part of the frame and its L2 holds that part's cells (xcd_q = tiles / 8, xcd_rem = tiles % 8)
     unsigned xcd_on, xcd_q, xcd_rem;
     // the tolerance translation unit (RTM_TOL): per tile of the launch 64 words — bit s of word p: "sub-pixel s of pixel p
-    // has a primary ray whose nearest hit last-bit differences could change" (prim_mask_kernel); null elsewhere
+    // has a primary ray whose nearest hit last-bit differences could change" (prim_prepass_kernel); null elsewhere
     const unsigned long long* __restrict__ prim_masks;
+    // ... and, from the same pre-pass, every sub-pixel's primary direction ([tile][sub-pixel][component][pixel] doubles):
+    // a lane that moves on to its next sub-pixel LOADS its direction instead of running the five correctly rounded
+    // divisions of src/Renderer.cpp:228-232 alone in its wave (some lane of a wave does about every 4.4 trips: 4 % of the
+    // frame).  Null: the directions are computed where they are needed, as before.
+    const double* __restrict__ prim_dirs;
     // grid kernel: one bit per (tile, sample, pixel) of the launch — "this sample's term is not all zeros and was stored";
     // zeroed before the launch, set with atomicOr, read by grid_finalize_kernel.  A term of (+-0, +-0, +-0) changes no sum
     // it is added to (the accumulator starts at +0 and no term is negative zero's only partner), so it is neither stored nor
@@ -290,6 +295,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         for (int k = 1; k < 9; ++k) pick = (lane == k) ? v9[k] : pick;
         cam[lane] = pick;
     }
+    {  // the spare slot: this tile's first entry of the pre-pass's direction table (primary_of below)
+        const unsigned tile_of_block = (SPLIT && blockIdx.x >= P.split_first) ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles
+                                                                               : blockIdx.x;
+        const double first = __longlong_as_double((long long)((unsigned long long)tile_of_block * (unsigned long long)(unsigned)(P.SS * P.SS)));
+        if (lane == 9) cam[9] = first;
+    }
     __syncthreads();
     if constexpr (LDS_TAB) {
         const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
@@ -388,11 +399,30 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     if constexpr (kPrimFix) {
         const unsigned tile_id = (SPLIT && blockIdx.x >= P.split_first) ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles
                                                                          : blockIdx.x;
-        const unsigned long long mask = P.prim_masks[(size_t)tile_id * 64 + (unsigned)lane];  // prim_mask_kernel, the same launch
+        const unsigned long long mask = P.prim_masks[(size_t)tile_id * 64 + (unsigned)lane];  // prim_prepass_kernel, the same launch
         prim_mask[lane] = mask;
         prim_fix = prim_flag_of(mask, (unsigned)sub_first);
     }
-    D3 pdir = primary_dir_lds(P, cam, x, y, sub_first / P.SS + 1, sub_first % P.SS + 1);
+    // The primary direction of sub-pixel `sub` of the tile's pixel `pl` (its lane number; px, py: its coordinates): from the
+    // pre-pass's table where there is one (wave-uniform choice), else computed here.
+    constexpr bool kPrimDirs = DEFER && !REUSE;  // the deferred-fold kernels (both translation units)
+    [[maybe_unused]] auto primary_of = [&](const unsigned pl, const int px, const int py, const unsigned sub) -> D3 {
+        if constexpr (kPrimDirs) {
+            if (P.prim_dirs != nullptr) {
+                // (the tile's first entry, parked in the camera block's spare LDS slot by the prologue: an integer
+                // division to recompute, and a register pair too many to keep across the loop)
+                // (a lane that is past its range keeps tracing dummies and keeps asking: its "next sub-pixel" may be one
+                // past the pixel's last — clamped, the table ends with the last tile's last sub-pixel)
+                const unsigned all = (unsigned)(P.SS * P.SS);
+                const unsigned long long first = (unsigned long long)__double_as_longlong(cam[9]);
+                const double* q = P.prim_dirs + (first + (sub < all ? sub : all - 1u)) * 192 + (pl & 63u);
+                return D3{q[0], q[64], q[128]};
+            }
+        }
+        return primary_dir_lds(P, cam, px, py, (int)(sub / (unsigned)P.SS) + 1, (int)(sub % (unsigned)P.SS) + 1);
+    };
+    D3 pdir = kPrimDirs ? primary_of((unsigned)lane, x, y, (unsigned)sub_first)
+                        : primary_dir_lds(P, cam, x, y, sub_first / P.SS + 1, sub_first % P.SS + 1);
     D3 org = P.cam_org, dir = pdir;
     int depth = 0;
     const RngPixelKey pkey = rng_pixel_key(P.seed_mult, pixel);
@@ -751,7 +781,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     const int sub = (int)(n / (unsigned)P.S);
                     int px, py;
                     pixel_xy(px, py);
-                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                    if constexpr (kPrimDirs) pdir = primary_of((unsigned)lane, px, py, (unsigned)sub);
+                    else pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
                     park[3 * 64 + lane] = pdir.x;
                     park[4 * 64 + lane] = pdir.y;
                     park[5 * 64 + lane] = pdir.z;
@@ -861,7 +892,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     const int sub = (int)((cur & 0xFFFFu) / (unsigned)P.S);
                     int px, py;
                     pixel_xy(px, py);
-                    pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
+                    if constexpr (kPrimDirs) pdir = primary_of((unsigned)lane, px, py, (unsigned)sub);
+                    else pdir = primary_dir_lds(P, cam, px, py, sub / P.SS + 1, sub % P.SS + 1);
                     park[3 * 64 + lane] = pdir.x;
                     park[4 * 64 + lane] = pdir.y;
                     park[5 * 64 + lane] = pdir.z;
@@ -906,7 +938,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         // s_st / S and sub / SS by multiplication (exact for operands below 2^16; a divisor of 1 has no magic)
                         const unsigned sub = P.S == 1 ? s_st : __umulhi(s_st, P.magic_S);
                         const unsigned sxm1 = P.SS == 1 ? sub : __umulhi(sub, P.magic_SS);
-                        dir = primary_dir_lds(P, cam, px, py, (int)sxm1 + 1, (int)(sub - sxm1 * (unsigned)P.SS) + 1);
+                        if constexpr (kPrimDirs) dir = primary_of((unsigned)v, px, py, sub);
+                        else dir = primary_dir_lds(P, cam, px, py, (int)sxm1 + 1, (int)(sub - sxm1 * (unsigned)P.SS) + 1);
                         rng = rng_open(vkey, s_st);
                         if constexpr (kPrimFix) prim_fix = prim_flag_of(prim_mask[v], sub);
                     }
@@ -1145,28 +1178,45 @@ __global__ __launch_bounds__(64) void steal_finalize_kernel(const RenderParams P
     store_pixel(P, valid, px, py, acc);
 }
 
-#if RTM_TOL
-// The tolerance translation unit's pre-pass, one wave per tile of the launch, lane = pixel: for every sub-pixel (the first
-// 64 of them) whether its primary ray — shared by its S samples, src/Renderer.cpp:224-232 — is one whose nearest hit
-// last-bit differences could change (rtm_path.h: primary_tie_risk; the shipped Cornell box has such rays along the
-// image's diagonals, where the seam of two wall spheres projects exactly).  The render kernel settles those rays'
-// primary hits with the reference's own arithmetic (nearest_hit_exactfp).
-__global__ __launch_bounds__(64) void prim_mask_kernel(const RenderParams P, unsigned long long* __restrict__ masks) {
+// The pre-pass of the deferred-fold kernels, one wave per tile of the launch, lane = pixel: every sub-pixel's primary direction
+// (src/Renderer.cpp:227-232: shared by the sub-pixel's S samples) goes to RenderParams::prim_dirs, computed HERE by all 64
+// lanes at once with the very function the render loop would call — so that a lane of the render kernel that moves on to its
+// next sub-pixel loads three doubles instead of running five correctly rounded divisions alone in its wave (about every 4.4
+// trips some lane of a wave does: 4 % of the frame; same bits by construction).  In the tolerance translation unit it also
+// leaves, per pixel, a bit per sub-pixel (the first 64 of them): "this primary ray is one whose nearest hit last-bit
+// differences could change" (rtm_path.h: primary_tie_risk; the shipped Cornell box has such rays along the image's
+// diagonals, where the seam of two wall spheres projects exactly) — the render kernel settles those rays' primary hits with
+// the reference's own arithmetic (nearest_hit_exactfp).
+__global__ __launch_bounds__(64) void prim_prepass_kernel(const RenderParams P, unsigned long long* __restrict__ masks,
+                                                          double* __restrict__ dirs) {
     const int lane = threadIdx.x;
     const unsigned tile = blockIdx.x;
+    auto store_dir = [&](const unsigned sub, const D3 d) {  // RenderParams::prim_dirs: [tile][sub-pixel][component][pixel]
+        double* q = dirs + ((size_t)tile * (unsigned)(P.SS * P.SS) + sub) * 192 + (unsigned)lane;
+        q[0] = d.x;
+        q[64] = d.y;
+        q[128] = d.z;
+    };
     const int x = (int)(tile % (unsigned)P.tiles_x) * 8 + (lane & 7);
     const int y = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);
     const double cam[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
-    SceneGlobal sc;
-    sc.v = P.scene;
-    unsigned long long mask = 0ull;
-    const unsigned subs = (unsigned)(P.SS * P.SS) < 64u ? (unsigned)(P.SS * P.SS) : 64u;
-    for (unsigned sub = 0; sub < subs; ++sub) {
+    [[maybe_unused]] unsigned long long mask = 0ull;
+    const unsigned all = (unsigned)(P.SS * P.SS);
+    for (unsigned sub = 0; sub < all; ++sub) {
+        if (dirs == nullptr && (masks == nullptr || sub >= 64u)) break;
         const D3 d = primary_dir_lds(P, cam, x, y, (int)(sub / (unsigned)P.SS) + 1, (int)(sub % (unsigned)P.SS) + 1);
-        mask |= primary_tie_risk(sc, P.cam_org, d) ? (1ull << sub) : 0ull;
-    }
-    masks[(size_t)tile * 64 + (unsigned)lane] = mask;
-}
+#if RTM_TOL
+        if (masks != nullptr && sub < 64u) {
+            SceneGlobal sc;
+            sc.v = P.scene;
+            mask |= primary_tie_risk(sc, P.cam_org, d) ? (1ull << sub) : 0ull;
+        }
 #endif
+        if (dirs != nullptr) store_dir(sub, d);
+    }
+#if RTM_TOL
+    if (masks != nullptr) masks[(size_t)tile * 64 + (unsigned)lane] = mask;
+#endif
+}
 
 }  // namespace RTM_NS

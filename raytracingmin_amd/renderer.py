@@ -71,9 +71,9 @@ class Renderer:
         row_end = self.data.height if row_end is None else row_end
         opt = self._options(row_begin, row_end, band)
         st = self.data.settings_c()
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 6)()
         _lib.check(_lib.lib().rtm_scratch_bytes(C.byref(st), self._scene_handle(), C.byref(opt), out), "rtm_scratch_bytes")
-        return dict(zip(("total", "terms", "records", "pipeline_state", "steal_rows"), (int(v) for v in out)))
+        return dict(zip(("total", "terms", "records", "pipeline_state", "steal_rows", "primary_table"), (int(v) for v in out)))
 
     def invalidate(self):
         if self._scene is not None:
