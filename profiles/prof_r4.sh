@@ -32,9 +32,9 @@ for d in ('fetch','write','mix','mix2','mix3'):
 for d in ('fetch','write'):
     for k,v in per_launch(d, lambda n: 'split_finalize' in n).items(): out['split_finalize.'+k]=v
     for k,v in per_launch(d, lambda n: 'steal_finalize' in n).items(): out['steal_finalize.'+k]=v
-    for k,v in per_launch(d, lambda n: 'prim_mask' in n).items(): out['prim_mask.'+k]=v
+    for k,v in per_launch(d, lambda n: 'prim_prepass' in n).items(): out['prim_mask.'+k]=v
 stats=[r for f in glob.glob('$O/trace/*/*_kernel_stats.csv') for r in csv.DictReader(open(f))]
-out['kernel_stats']=[r for r in stats if 'render' in r['Name'] or 'split' in r['Name'] or 'steal' in r['Name'] or 'prim_mask' in r['Name']]
+out['kernel_stats']=[r for r in stats if 'render' in r['Name'] or 'split' in r['Name'] or 'steal' in r['Name'] or 'prim_prepass' in r['Name']]
 try:  # the figure bench.py replays as roofline.traffic (profiles/latest_traffic.json)
     kb=lambda k: out.get(k,0.0)
     tr={'render_fetch_kb':kb('FETCH_SIZE'),'render_write_kb':kb('WRITE_SIZE'),

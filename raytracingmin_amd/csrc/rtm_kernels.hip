@@ -324,7 +324,7 @@ constexpr double kGridDdTol = 4e-7;  // |dir.dir - 1| the pads cover: twice what
 static double grid_cells_per_sphere() {
     static const double v = [] {
         const char* e = std::getenv("RTM_DEBUG_GRID_CELLS");  // tuning knob: cells per sphere; 0 = build no grid
-        return e ? std::strtod(e, nullptr) : 2.0;
+        return e ? std::strtod(e, nullptr) : 1.5;  // (round 4, with the next-cell fill: flat between 1.35 and 1.65, 2.0 is 2.3 % slower — profiles/r4/grid_cells.txt)
     }();
     return v;
 }

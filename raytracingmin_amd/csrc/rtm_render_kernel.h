@@ -57,7 +57,7 @@ struct RenderParams {
     // the tolerance translation unit (RTM_TOL): per tile of the launch 64 words — bit s of word p: "sub-pixel s of pixel p
     // has a primary ray whose nearest hit last-bit differences could change" (prim_prepass_kernel); null elsewhere
     const unsigned long long* __restrict__ prim_masks;
-    // ... and, from the same pre-pass, every sub-pixel's primary direction ([tile][sub-pixel][component][pixel] doubles):
+    // ... and, from the same pre-pass, every sub-pixel's primary direction ([tile][pixel][sub-pixel][component] doubles):
     // a lane that moves on to its next sub-pixel LOADS its direction instead of running the five correctly rounded
     // divisions of src/Renderer.cpp:228-232 alone in its wave (some lane of a wave does about every 4.4 trips: 4 % of the
     // frame).  Null: the directions are computed where they are needed, as before.
@@ -151,8 +151,12 @@ __device__ __forceinline__ D3 primary_dir_lds(const RenderParams& P, const doubl
     const double m = (double)__builtin_sqrtf(len2);
     return D3{vx / m, vy / m, vz / m};                          // src/Ray.h:70-72
 #else
-    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / P.W - 1.0;
-    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / P.H - 1.0;
+    int w = P.W, h = P.H;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(w), "+s"(h));  // (opaque: their conversions to double are not worth a register pair each across the render loop)
+#endif
+    const double px = 2.0 * ((double)x + (double)(P.rate * (float)sx)) / w - 1.0;
+    const double py = 2.0 * ((double)y + (double)(P.rate * (float)sy)) / h - 1.0;
     const D3 ax = d3(cam[0], cam[1], cam[2]), by = d3(cam[3], cam[4], cam[5]), cz = d3(cam[6], cam[7], cam[8]);
     return normalize((ax * px + by * py) + cz);
 #endif
@@ -352,6 +356,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     // "the contracted search does not find the reference's hit for this sub-pixel's primary ray" (an exact tie in real
     // arithmetic: rtm_path.h, nearest_hit_exactfp) —, in LDS so that a lane that steals a sample of another pixel finds it.
     // Sub-pixels from 64 up have no bit and always take the exact loop.
+#ifndef RTM_DIR_PIXEL_MAJOR
+#define RTM_DIR_PIXEL_MAJOR 0  // layout of RenderParams::prim_dirs (A/B: profiles/r4/dir_table_ab.txt)
+#endif
+#ifndef RTM_DIR_NT
+#define RTM_DIR_NT 0           // non-temporal reads of it
+#endif
 #ifndef RTM_TOL_PRIMFIX
 #define RTM_TOL_PRIMFIX 1  // (A/B switch: 0 compiles the exact-tie handling out — NOT within tolerance on the Cornell diagonals)
 #endif
@@ -415,8 +425,23 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 // past the pixel's last — clamped, the table ends with the last tile's last sub-pixel)
                 const unsigned all = (unsigned)(P.SS * P.SS);
                 const unsigned long long first = (unsigned long long)__double_as_longlong(cam[9]);
-                const double* q = P.prim_dirs + (first + (sub < all ? sub : all - 1u)) * 192 + (pl & 63u);
-                return D3{q[0], q[64], q[128]};
+                unsigned col = pl & 63u;
+                asm volatile("" : "+v"(col));  // (opaque: hipcc otherwise hoists the lane's table address out of the render
+                                               // loop into a register pair it then spills — 28 GB of scratch reloads per frame)
+#if RTM_DIR_PIXEL_MAJOR
+                // [tile][pixel][sub-pixel][component]: a lane's three doubles share a line
+                const double* q = P.prim_dirs + ((first * 64u + (unsigned long long)col * all) + (sub < all ? sub : all - 1u)) * 3;
+                constexpr int kStep = 1;
+#else
+                // [tile][sub-pixel][component][pixel]
+                const double* q = P.prim_dirs + (first + (sub < all ? sub : all - 1u)) * 192 + col;
+                constexpr int kStep = 64;
+#endif
+#if RTM_DIR_NT
+                return D3{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + kStep), __builtin_nontemporal_load(q + 2 * kStep)};
+#else
+                return D3{q[0], q[kStep], q[2 * kStep]};
+#endif
             }
         }
         return primary_dir_lds(P, cam, px, py, (int)(sub / (unsigned)P.SS) + 1, (int)(sub % (unsigned)P.SS) + 1);
@@ -1191,11 +1216,18 @@ __global__ __launch_bounds__(64) void prim_prepass_kernel(const RenderParams P, 
                                                           double* __restrict__ dirs) {
     const int lane = threadIdx.x;
     const unsigned tile = blockIdx.x;
-    auto store_dir = [&](const unsigned sub, const D3 d) {  // RenderParams::prim_dirs: [tile][sub-pixel][component][pixel]
-        double* q = dirs + ((size_t)tile * (unsigned)(P.SS * P.SS) + sub) * 192 + (unsigned)lane;
-        q[0] = d.x;
-        q[64] = d.y;
-        q[128] = d.z;
+    auto store_dir = [&](const unsigned sub, const D3 d) {  // RenderParams::prim_dirs: [tile][pixel][sub-pixel][component]
+        const unsigned all_s = (unsigned)(P.SS * P.SS);
+#if RTM_DIR_PIXEL_MAJOR
+        double* q = dirs + (((size_t)tile * 64 + (unsigned)lane) * all_s + sub) * 3;
+        constexpr int kStep = 1;
+#else
+        double* q = dirs + ((size_t)tile * all_s + sub) * 192 + (unsigned)lane;
+        constexpr int kStep = 64;
+#endif
+        __builtin_nontemporal_store(d.x, q);
+        __builtin_nontemporal_store(d.y, q + kStep);
+        __builtin_nontemporal_store(d.z, q + 2 * kStep);
     };
     const int x = (int)(tile % (unsigned)P.tiles_x) * 8 + (lane & 7);
     const int y = band_row(P, (int)(tile / (unsigned)P.tiles_x), lane >> 3);

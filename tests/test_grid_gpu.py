@@ -491,6 +491,7 @@ def test_grid_counts_its_sphere_tests_and_scratch_is_announced(rtm, oracle):
     sb = r.scratch_bytes()
     tiles = (160 // 8) * (96 // 8)
     assert sb["terms"] == tiles * (8 * 64 * 32 + 8 * 8) and sb["records"] == 0 and sb["total"] == sb["terms"]  # slots + "term stored" bits
+    assert sb["primary_table"] == 0  # (the deferred-fold kernels' table: not the grid kernel's)
     deep = rtm.Renderer(data, mode="repaired", max_bounces=-1, seed=2).scratch_bytes()
     assert deep["records"] == 65536 * 960 * 4 + 64  # the grid kernel's records are 4 bytes wide whatever n
     x = rtm.Renderer(data, mode="repaired", max_bounces=8, seed=2, variant=12).scratch_bytes()
@@ -500,3 +501,7 @@ def test_grid_counts_its_sphere_tests_and_scratch_is_announced(rtm, oracle):
     head = rtm.Renderer(cornell, mode="repaired", max_bounces=8, seed=2).scratch_bytes()
     print("headline frame:", {k: f"{v / 2**30:.2f} GiB" for k, v in head.items()})
     assert head["terms"] > 2**30 and head["steal_rows"] > 2**31 and head["records"] == 0
+    assert head["primary_table"] == 32400 * 16 * 3 * 64 * 8  # a direction per (tile, sub-pixel, component, pixel)
+    assert head["total"] == head["terms"] + head["steal_rows"] + head["primary_table"]
+    tol = rtm.Renderer(cornell, mode="repaired", max_bounces=8, seed=2, variant=18).scratch_bytes()
+    assert tol["primary_table"] == head["primary_table"] + 32400 * 64 * 8  # + a mask word per pixel
