@@ -741,7 +741,7 @@ def main():
         if world == 1 and headline and args.variant in (0, 18) and os.path.exists(tpath):
             tj = json.load(open(tpath))
             replay = {"traffic": tj["bytes_per_launch"],  # PMC bytes of a committed rocprofv3 --pmc pass of this command
-                      "traffic_source": {"measured_in_run": False, "file": "profiles/latest_traffic.json",
+                      "traffic_source": {"measured_in_run": False, "file": os.path.relpath(tpath, ROOT),
                                          "profile": tj.get("source", "profiles/r1/default_pmc_summary.json"),
                                          "what": "FETCH_SIZE + WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md prescribes",
                                          "note": tj.get("note")}}

@@ -870,6 +870,9 @@ __device__ __forceinline__ void object_chunk(const Scene& sc, const int i0, cons
 #ifndef RTM_GRID_SPILL
 #define RTM_GRID_SPILL 1
 #endif
+#ifndef RTM_GRID_EARLY_END
+#define RTM_GRID_EARLY_END 1
+#endif
 constexpr int kGridBatch = RTM_GRID_K;  // records in flight per trip of the walk (profiles/r3/grid_crossover.txt)
 #ifndef RTM_GRID_SHADE_AT
 #define RTM_GRID_SHADE_AT 5
@@ -1157,6 +1160,10 @@ struct GridWalk {
             dis = accept ? t : dis;
             best = accept ? i : best;
         }
+#if RTM_GRID_EARLY_END
+        // the walk's end seen in the trip that settles it, not one trip later (the test at the top of the next one)
+        if (pending == 0u && j >= jend && (dis <= t_exit || !next_ok)) return false;
+#endif
         return true;
     }
 };
