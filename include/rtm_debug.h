@@ -16,7 +16,7 @@ extern "C" {
 #endif
 
 /* device sqrt / sqrtf / division / sin / cos and the exact-fast forms on caller data; `op` as in
- * math_probe_kernel (csrc/rtm_seam_kernels.h); ops 32..38: the tolerance row's arithmetic — one-ulp square root, division and
+ * math_probe_kernel (csrc/rtm_seam_kernels.h); ops 32..40: the tolerance row's arithmetic — one-ulp square root, division and
  * reciprocal, a contracted multiply-add, its sin / cos, the unfused fold step (csrc/rtm_kernels_tol.hip) */
 int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, double* out);
 /* exhaustive device self-checks; *mismatches = number of failing inputs (kind 0: fast sqrtf) */

@@ -216,6 +216,43 @@ __device__ __forceinline__ void sincos_small_k(const K& k, const double x, doubl
 __device__ __forceinline__ void sincos_small(const double x, double& sn, double& cs) {
     sincos_small_k(TrigFromRegs{}, x, sn, cs);
 }
+#if RTM_TOL
+// The tolerance unit's sin / cos of r1 = 2 pi (m 2^-24), m the draw's 24-bit integer (src/Renderer.cpp:88,93-94), without the
+// Cody-Waite reduction: the quadrant and the offset from it are EXACT in the draw's own units — q = rint(m 2^-22),
+// f = m 2^-22 - q in [-1/2, 1/2] — so the reduced argument is one rounded product f (pi/2) (relative error 2^-53; the
+// reference's own r1 carries 2^-53 of up to 2 pi) and the kernels run without their low word.  Same polynomials as above:
+// within 8e-16 of the exact unit's sin / cos of the ROUNDED r1 over all 2^23 draws (tests/test_tolerance_gpu.py; half an ulp
+// of r1 in [4, 8) is 4.4e-16 of that); 14 instructions fewer.
+template <class K>
+__device__ __forceinline__ void sincos_turn24_k(const K& k, const double m24, double& sn, double& cs) {
+    const double x4 = m24 * 0x1p-22;
+    const double dn = __builtin_rint(x4);
+    const double hi = (x4 - dn) * k[1];
+    const int q = (int)dn;
+    const double t = hi * hi;
+    const double h = t * 0.5;
+    const double c1 = 1.0 - h;
+    const double c3 = (1.0 - c1) - h;
+    double p = __builtin_fma(t, k[4], k[5]);
+    p = __builtin_fma(t, p, k[6]);
+    p = __builtin_fma(t, p, k[7]);
+    p = __builtin_fma(t, p, k[8]);
+    p = __builtin_fma(t, p, k[9]);
+    const double cosv = c1 + __builtin_fma(t * t, p, c3);
+    double s = __builtin_fma(t, k[10], k[11]);
+    s = __builtin_fma(t, s, k[12]);
+    s = __builtin_fma(t, s, k[13]);
+    s = __builtin_fma(t, s, k[14]);
+    const double v = hi * t;  // sin = hi - v (1/6 - t s)
+    const double sinv = __builtin_fma(v, __builtin_fma(t, s, k[15]), hi);
+    const bool odd = (q & 1) != 0;
+    const int flip = (q & 2) ? (int)0x80000000 : 0;
+    const double so = odd ? cosv : sinv;
+    const double co = odd ? -sinv : cosv;
+    sn = __hiloint2double(__double2hiint(so) ^ flip, __double2loint(so));
+    cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
+}
+#endif
 
 // ---- build-defined counter RNG; must agree with rtm_rng_u01 on the host ----
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -51,7 +51,8 @@ static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipSt
 // rtm_debug_math_probe ops 32..: this translation unit's arithmetic on caller data (tests/test_tolerance_gpu.py measures the
 // distance to the correctly rounded results in ulps).  32 the unscaled square root, 33 x / y by reciprocal, 34 the
 // reciprocal alone, 35 x * y + 1.0 (contracted here: the other translation unit's op 7 must not be), 36 / 37 sin / cos of the
-// branch-free sincos as compiled here, 38 one level of the fold (x * y + 0.25: must NOT be contracted)
+// branch-free sincos as compiled here, 38 one level of the fold (x * y + 0.25: must NOT be contracted), 39 / 40 sin / cos of
+// 2 pi (x 2^-24) by the quadrant-exact sequence the shading block uses (x: a draw's 24-bit integer)
 __global__ void tol_math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b, size_t n,
                                       double* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,6 +67,8 @@ __global__ void tol_math_probe_kernel(int op, const double* __restrict__ a, cons
         case 36: sincos_small(x, s, c); r = s; break;
         case 37: sincos_small(x, s, c); r = c; break;
         case 38: r = fold_step(d3(x, x, x), d3(y, y, y), d3(0.25, 0.25, 0.25)).y; break;
+        case 39: sincos_turn24_k(TrigFromRegs{}, x, s, c); r = s; break;
+        case 40: sincos_turn24_k(TrigFromRegs{}, x, s, c); r = c; break;
         default: break;
     }
     out[i] = r;

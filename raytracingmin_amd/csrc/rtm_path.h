@@ -266,6 +266,18 @@ struct MathSpecT {
         else
             sincos_small(x, sn, cs);
     }
+    // sin / cos of r1 = 2 pi u for the draw u = m24 2^-24 (src/Renderer.cpp:88: (2 pi 2^-24) m is the same correctly
+    // rounded product as 2 pi (m 2^-24))
+    __device__ __forceinline__ void sincos_draw(double m24, double& sn, double& cs) {
+#if RTM_TOL
+        if (trig_lds)
+            sincos_turn24_k(TrigFromLds{trig_lds}, m24, sn, cs);
+        else
+            sincos_turn24_k(TrigFromRegs{}, m24, sn, cs);
+#else
+        sincos_r1((6.283185307179586 * 0x1p-24) * m24, sn, cs);
+#endif
+    }
     // Magnitude (src/Ray.h:67-69) with the unscaled float sqrt
     __device__ __forceinline__ double magnitude_spec(D3 a) {
         const float len2 = (float)(a.x * a.x + a.y * a.y + a.z * a.z);
@@ -428,6 +440,7 @@ struct MathRefI {
         else
             sincos(x, &sn, &cs);
     }
+    __device__ __forceinline__ void sincos_draw(double m24, double& sn, double& cs) { sincos_r1((6.283185307179586 * 0x1p-24) * m24, sn, cs); }
 };
 struct MathFastI {
     static constexpr bool bad = false;
@@ -437,6 +450,7 @@ struct MathFastI {
     __device__ __forceinline__ double sqrt64_unit(double x) { return MathFast::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathFast::div3(a, y); }
     __device__ __forceinline__ void sincos_r1(double x, double& sn, double& cs) { sincos(x, &sn, &cs); }
+    __device__ __forceinline__ void sincos_draw(double m24, double& sn, double& cs) { sincos_r1((6.283185307179586 * 0x1p-24) * m24, sn, cs); }
 };
 
 // src/Ray.h:67-72 through a policy
@@ -1405,7 +1419,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
     out.draws = 3;
     // :88 r1 = 2 PI u with u = m * 2^-24: (2 PI * 2^-24) * m is the same correctly rounded product as 2 PI * (m * 2^-24)
-    const double r1 = (6.283185307179586 * 0x1p-24) * rng_next_m(rng);
+    const double m24 = rng_next_m(rng);  // (r1 is formed where its sin / cos are taken: sincos_draw)
     const double r2 = rng_next(rng);                      // :89
 #if RTM_OPT_TRIGLOAD
     TrigFixWord fixw{0u, 0};
@@ -1431,7 +1445,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
             double ux, uz;
             m.normalize_xz(w.z, -w.x, ux, uz);
             const double vx = w.y * uz, vy = -w.x * uz + w.z * ux, vz = -(w.y * ux);
-            m.sincos_r1(r1, sn, cs);
+            m.sincos_draw(m24, sn, cs);
 #if RTM_OPT_TRIGLOAD
             if (sc.v.trig_fix) trig_fix_apply(fixw, sn, cs);  // wave-uniform
 #else
@@ -1456,7 +1470,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
         u = m.normalize_y0(c);  // c.y = (-0)*w.z + 0*w.x is a signed zero for finite w
     }
     const D3 v = cross(w, u);  // :102
-    m.sincos_r1(r1, sn, cs);
+    m.sincos_draw(m24, sn, cs);
 #if RTM_OPT_TRIGLOAD
     if (sc.v.trig_fix) trig_fix_apply(fixw, sn, cs);  // wave-uniform
 #else

@@ -69,6 +69,18 @@ def test_tolerance_arithmetic_is_within_its_stated_ulps(rtm):
     for op_tol, op_exact in ((36, 12), (37, 13)):
         a, b = _probe(rtm, op_tol, r1), _probe(rtm, op_exact, r1)
         assert np.max(np.abs(a - b)) <= 2.3e-16
+    # ... and what the shading block of this row actually runs: the quadrant-exact sequence on the draw's integer
+    # (csrc/rtm_device.h sincos_turn24_k), over EVERY possible draw, against the exact unit's sin / cos of r1
+    m_all = (2.0 * np.arange(1 << 23, dtype=np.float64) + 1.0)
+    r1_all = (6.283185307179586 * 2.0 ** -24) * m_all
+    worst_trig = 0.0
+    for op_tol, op_exact in ((39, 12), (40, 13)):
+        a, b = _probe(rtm, op_tol, m_all), _probe(rtm, op_exact, r1_all)
+        worst_trig = max(worst_trig, float(np.max(np.abs(a - b))))
+    print(f"quadrant-exact sin / cos over all 2^23 draws: max |difference| from the exact unit's {worst_trig:.3e}")
+    # the reference takes sin / cos of the ROUNDED r1 (half an ulp of [4, 8): 4.4e-16 off 2 pi u), this sequence of 2 pi u
+    # itself, each result within two ulp: 4.4e-16 + 3 x 1.1e-16
+    assert worst_trig <= 8e-16
 
 
 def _frames(rtm, data, mb, seed, rows=None, band=None):
