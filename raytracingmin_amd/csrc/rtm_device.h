@@ -206,10 +206,11 @@ __device__ __forceinline__ void sincos_small_k(const K& k, const double x, doubl
     const double w = __builtin_fma(t, __builtin_fma(v, s, lo * 0.5), nlo);
     const double sinv = hi - __builtin_fma(v, k[15], w);
     // quadrant: sin <- (q odd ? cos : sin), cos <- (q odd ? -sin : cos); both negated for q & 2
-    const bool odd = (q & 1) != 0;
+    // (bit selects: four v_cndmask_b32_e32 back to back, what hipcc makes of ?: on doubles, cost three times as much — LaneMask)
+    const LaneMask odd = lane_mask((q & 1) != 0);
     const int flip = (q & 2) ? (int)0x80000000 : 0;
-    const double so = odd ? cosv : sinv;
-    const double co = odd ? -sinv : cosv;
+    const double so = sel_f64(odd, cosv, sinv);
+    const double co = sel_f64(odd, -sinv, cosv);
     sn = __hiloint2double(__double2hiint(so) ^ flip, __double2loint(so));
     cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
 }
@@ -245,10 +246,11 @@ __device__ __forceinline__ void sincos_turn24_k(const K& k, const double m24, do
     s = __builtin_fma(t, s, k[14]);
     const double v = hi * t;  // sin = hi - v (1/6 - t s)
     const double sinv = __builtin_fma(v, __builtin_fma(t, s, k[15]), hi);
-    const bool odd = (q & 1) != 0;
+    // (bit selects: four v_cndmask_b32_e32 back to back, what hipcc makes of ?: on doubles, cost three times as much — LaneMask)
+    const LaneMask odd = lane_mask((q & 1) != 0);
     const int flip = (q & 2) ? (int)0x80000000 : 0;
-    const double so = odd ? cosv : sinv;
-    const double co = odd ? -sinv : cosv;
+    const double so = sel_f64(odd, cosv, sinv);
+    const double co = sel_f64(odd, -sinv, cosv);
     sn = __hiloint2double(__double2hiint(so) ^ flip, __double2loint(so));
     cs = __hiloint2double(__double2hiint(co) ^ flip, __double2loint(co));
 }

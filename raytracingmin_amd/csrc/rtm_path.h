@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     // :88 r1 = 2 PI u with u = m * 2^-24: (2 PI * 2^-24) * m is the same correctly rounded product as 2 PI * (m * 2^-24)
     const double m24 = rng_next_m(rng);  // (r1 is formed where its sin / cos are taken: sincos_draw)
     const double r2 = rng_next(rng);                      // :89
-#if RTM_OPT_TRIGLOAD
+#if RTM_OPT_TRIGLOAD && !RTM_TOL  // (the tolerance unit takes the device's sin / cos: launch_tol)
     TrigFixWord fixw{0u, 0};
     if (sc.v.trig_fix) fixw = trig_fix_load(sc.v.trig_fix, rng);  // wave-uniform; consumed after the sincos
 #endif
@@ -1446,7 +1446,8 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
             m.normalize_xz(w.z, -w.x, ux, uz);
             const double vx = w.y * uz, vy = -w.x * uz + w.z * ux, vz = -(w.y * ux);
             m.sincos_draw(m24, sn, cs);
-#if RTM_OPT_TRIGLOAD
+#if RTM_TOL
+#elif RTM_OPT_TRIGLOAD
             if (sc.v.trig_fix) trig_fix_apply(fixw, sn, cs);  // wave-uniform
 #else
             if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);
@@ -1471,7 +1472,8 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
     }
     const D3 v = cross(w, u);  // :102
     m.sincos_draw(m24, sn, cs);
-#if RTM_OPT_TRIGLOAD
+#if RTM_TOL
+#elif RTM_OPT_TRIGLOAD
     if (sc.v.trig_fix) trig_fix_apply(fixw, sn, cs);  // wave-uniform
 #else
     if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);  // wave-uniform
