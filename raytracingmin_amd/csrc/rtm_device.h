@@ -146,6 +146,12 @@ struct TrigConsts {
     double s4, s3, s2, s1, s0, third;  // sin kernel, highest degree first; third = -1/6
 };
 constexpr int kTrigConstCount = 16;
+// Behind them in the same LDS block: the Normalize of a vector whose squared length, as a float, is within a few ulps of 1
+// (a bounce direction: src/Renderer.cpp:103-107) — kUnitWindow float bit patterns from kUnitWindowFirst on, for each the
+// magnitude (double)sqrtf(len2) and its refined reciprocal as the policies' own sequences give them (fill_shade_consts).
+constexpr int kUnitWindow = 16;
+constexpr uint32_t kUnitWindowFirst = 0x3F7FFFF8u;  // 1.0f - 8 ulps ... 1.0f + 7 ulps (observed over 4e6 bounces: -4 .. +2)
+constexpr int kShadeConstCount = kTrigConstCount + 2 * kUnitWindow;  // doubles of LDS a shading kernel sets aside
 __host__ __device__ __forceinline__ constexpr TrigConsts trig_consts() {
     return TrigConsts{0x1.45f306dc9c883p-1, 0x1.921fb54442d18p+0, 0x1.1a62633145c00p-54, 0x1.b839a252049c0p-104,
                       -0x1.907db46cc5e42p-37, 0x1.1eeb69037ab78p-29, -0x1.27e4fa17f65f6p-22, 0x1.a01a019f4ec90p-16,

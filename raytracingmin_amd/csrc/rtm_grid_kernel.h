@@ -55,11 +55,11 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
     double* cam = reinterpret_cast<double*>(lds_raw);  // 9 camera doubles + pad
-    double* trig = cam + 10;                           // 16 sincos constants
-    RecT* rec = reinterpret_cast<RecT*>(trig + kTrigConstCount);
+    double* trig = cam + 10;                           // the shading constants (sincos, near-unit Normalize)
+    RecT* rec = reinterpret_cast<RecT*>(trig + kShadeConstCount);
     unsigned* next_unit = reinterpret_cast<unsigned*>(rec + LDS_D * 64);
     unsigned char* queue = reinterpret_cast<unsigned char*>(next_unit + 4);  // the walks' candidate queue (16-byte aligned)
-    if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
+    fill_shade_consts(trig, lane);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
         double pick = v9[0];

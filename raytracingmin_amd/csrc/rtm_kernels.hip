@@ -1064,7 +1064,7 @@ static size_t debug_lds_pad() {
 // chunk, packed records for a depth cap of at most 8 (PACK8), by position for any depth (PACKL)
 template <bool SPLIT>
 static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
+    const size_t tab = lds_table_bytes(P.scene.n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
     constexpr size_t tag = SPLIT ? kFoldTagBytes : 0;
     if (P.max_bounces >= 0 && P.max_bounces <= 8)
         render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
@@ -1078,7 +1078,7 @@ constexpr size_t kStealLdsBytes = 2 * 64 * sizeof(unsigned);  // STEAL: every pi
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
           bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false, bool STEAL = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
+    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kShadeConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad() + (SPLIT ? kFoldTagBytes : 0);
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
@@ -1177,7 +1177,7 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
             return;
         }
         case kVariantPrimaryReuse: {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
-            const size_t lds = lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+            const size_t lds = lds_table_bytes(n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
                                kFoldQueueBytes + debug_lds_pad();
             if (n < 8)
                 render_tiles_kernel<MathFast, true, -8, uint8_t, 16, 4, true, false, true, false, true, false, true>
@@ -1995,7 +1995,7 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const Rende
     P.nz_bits = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + chunk * grid_tile_term_bytes(P.total_samples));
     const bool deep = needs_pool(P);
     const bool planes = P.scene.plane != nullptr;
-    const size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
+    const size_t lds = (10 + kShadeConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
                        GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
     for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
         const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);

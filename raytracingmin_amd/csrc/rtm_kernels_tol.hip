@@ -30,7 +30,7 @@ namespace rtm_tol {
 
 template <int UNROLL, bool SPLIT>
 static void launch_one(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
-    const size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+    const size_t lds = lds_table_bytes(P.scene.n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
                        kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) /* prim_mask */ + lds_pad;
     // <M, LDS_TAB, UNROLL, RecT, LDS_D, WPE, PARK, STAMP, PACK8, SPLIT, DEFER, PACKL, REUSE, PLANES, STEAL>
     render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, false, true>

@@ -115,6 +115,20 @@ __device__ __forceinline__ void seq_sqrt_batch(const double (&x)[K], double (&ou
 #endif
 }
 
+// The LDS constants of a shading kernel: the 16 sincos constants and the near-unit Normalize table (rtm_device.h); lanes
+// 0 .. 31 of a wave each write their share.  The table's entries are what div3_by_magnitude computes for those squared
+// lengths, instruction for instruction.
+__device__ __forceinline__ void fill_shade_consts(double* consts, const int lane) {
+    if (lane < kTrigConstCount) {
+        consts[lane] = TrigFromRegs{}[lane];
+    } else if (lane < kTrigConstCount + kUnitWindow) {
+        const int k = lane - kTrigConstCount;
+        const double y = (double)sqrtf_fast(__uint_as_float(kUnitWindowFirst + (uint32_t)k));
+        consts[kTrigConstCount + 2 * k] = y;
+        consts[kTrigConstCount + 2 * k + 1] = seq_rcp(y);
+    }
+}
+
 // MathRef: the compiler's IEEE expansions (v_div_scale/v_div_fmas/v_div_fixup, scaled rsq+NR sqrt).
 struct MathRef {
     static __device__ __forceinline__ double sqrt64(double x) { return ::sqrt(x); }
@@ -321,6 +335,34 @@ struct MathSpecT {
             return div3(a, magnitude_spec(a));
         }
     }
+    // Normalize of a bounce direction (src/Renderer.cpp:103-107): a combination of an orthonormal basis whose vectors went
+    // through the float-rounded Normalize themselves, so its squared length, as a float, is one of a handful of values
+    // around 1 (-4 .. +2 ulps over 4e6 bounces) — the float square root, its correction and the reciprocal's refinement are
+    // a 16-byte LDS read instead of a dozen instructions, three and a half of them transcendental-rate.  Same values:
+    // the table holds what div3_by_magnitude computes (fill_shade_consts).  A length outside the window trips `bad`.
+    __device__ __forceinline__ D3 normalize_near_unit(D3 a) {
+        if constexpr (GUARD) {
+            if (trig_lds) {
+                const double sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
+                const unsigned k = __float_as_uint((float)(sx + sy + sz)) - kUnitWindowFirst;
+#if RTM_TOL
+                bad = bad | (k >= (unsigned)kUnitWindow);
+#else
+                unsigned lo = (unsigned)__double2hiint(sx);
+                const unsigned hy = (unsigned)__double2hiint(sy), hz = (unsigned)__double2hiint(sz);
+                lo = hy < lo ? hy : lo;
+                lo = hz < lo ? hz : lo;
+                bad = bad | (k >= (unsigned)kUnitWindow) | (lo < 0x0DF00000u);  // see div3_by_magnitude
+#endif
+                const double2 yr = reinterpret_cast<const double2*>(trig_lds + kTrigConstCount)[k & (unsigned)(kUnitWindow - 1)];
+                auto one = [&](double x) {
+                    return seq_quot(x, yr.x, yr.y);
+                };
+                return D3{one(a.x), one(a.y), one(a.z)};
+            }
+        }
+        return normalize(a);
+    }
     // Normalize of a vector whose y component is a (signed) zero — Cross((0,1,0), w) for finite w:
     // y*y adds +0 to the squared length and +-0 / m is the same +-0, so only x and z are divided.
     // Anything else in y (NaN from a non-finite w) trips `bad`.
@@ -430,6 +472,7 @@ struct MathRefI {
     const double* trig_lds = nullptr;
     __device__ __forceinline__ D3 normalize(D3 a) { return MathRef::div3(a, magnitude(a)); }
     __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
+    __device__ __forceinline__ D3 normalize_near_unit(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathRef::sqrt64(x); }
     __device__ __forceinline__ double sqrt64_unit(double x) { return MathRef::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathRef::div3(a, y); }
@@ -446,6 +489,7 @@ struct MathFastI {
     static constexpr bool bad = false;
     __device__ __forceinline__ D3 normalize(D3 a) { return MathFast::div3(a, magnitude(a)); }
     __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
+    __device__ __forceinline__ D3 normalize_near_unit(D3 a) { return normalize(a); }
     __device__ __forceinline__ double sqrt64(double x) { return MathFast::sqrt64(x); }
     __device__ __forceinline__ double sqrt64_unit(double x) { return MathFast::sqrt64(x); }
     __device__ __forceinline__ D3 div3(D3 a, double y) { return MathFast::div3(a, y); }
@@ -1453,8 +1497,8 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
             if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);
 #endif
             const double s1 = m.sqrt64_unit(1.0 - r2);
-            out.dir = normalize_i(m, d3(((ux * cs) * r2s + (vx * sn) * r2s) + w.x * s1, (vy * sn) * r2s + w.y * s1,
-                                        ((uz * cs) * r2s + (vz * sn) * r2s) + w.z * s1));  // :103-107
+            out.dir = m.normalize_near_unit(d3(((ux * cs) * r2s + (vx * sn) * r2s) + w.x * s1, (vy * sn) * r2s + w.y * s1,
+                                               ((uz * cs) * r2s + (vz * sn) * r2s) + w.z * s1));  // :103-107
             out.org = hit_point;
             out.ctr = rng.ctr;
             return;
@@ -1478,7 +1522,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
 #else
     if (sc.v.trig_fix) apply_trig_fix(sc.v.trig_fix, rng, sn, cs);  // wave-uniform
 #endif
-    out.dir = normalize_i(m, (u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64_unit(1.0 - r2));  // :103-107
+    out.dir = m.normalize_near_unit((u * cs) * r2s + (v * sn) * r2s + w * m.sqrt64_unit(1.0 - r2));  // :103-107
     out.org = hit_point;
     out.ctr = rng.ctr;
 }

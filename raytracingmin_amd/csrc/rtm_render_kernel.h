@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
-    double* park = trig + kTrigConstCount;   // 16 sincos constants
+    double* park = trig + kShadeConstCount;  // the shading constants (sincos, near-unit Normalize)
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
     // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
     uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
     if constexpr (DEFER) fq_pend[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
-    if (lane < kTrigConstCount) trig[lane] = TrigFromRegs{}[lane];
+    fill_shade_consts(trig, lane);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
         double pick = v9[0];
