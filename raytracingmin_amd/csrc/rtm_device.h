@@ -170,6 +170,15 @@ struct TrigFromRegs {
         return t[i];
     }
 };
+// What a shading kernel hands the math policies: its LDS copy of the sincos constants and, behind it when the kernel has
+// room for one (the any-depth kernels run at 10 072 bytes of LDS per wave: 16 waves per CU end at 10 240), the near-unit
+// Normalize table.  A bare pointer converts to "constants only".
+struct ShadeLds {
+    const double* trig = nullptr;
+    const double* unit = nullptr;
+    __device__ __forceinline__ ShadeLds() {}
+    __device__ __forceinline__ ShadeLds(const double* t, bool with_unit = false) : trig(t), unit(with_unit && t ? t + kTrigConstCount : nullptr) {}
+};
 struct TrigFromLds {
     const double* p;
     __device__ __forceinline__ double operator[](int i) const { return p[i]; }

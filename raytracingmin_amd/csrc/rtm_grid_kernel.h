@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
             RTM_GRID_OCC(8);
             if constexpr (COUNT) n_tests += walk.tests;
             D3 term;
-            bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+            bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, ShadeLds(trig, true));
             if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
                 cont = false;
                 term = d3(0, 0, 0);

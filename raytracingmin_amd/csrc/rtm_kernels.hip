@@ -1060,16 +1060,17 @@ static size_t debug_lds_pad() {
     return pad;
 }
 
+constexpr size_t kUnitTableBytes = (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);  // rtm_device.h: the near-unit Normalize table
 // Scenes that hold planes (render_view: up to kLdsTableMaxSpheres objects): the deferred-fold kernels with the object
 // chunk, packed records for a depth cap of at most 8 (PACK8), by position for any depth (PACKL)
 template <bool SPLIT>
 static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    const size_t tab = lds_table_bytes(P.scene.n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
+    const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
     constexpr size_t tag = SPLIT ? kFoldTagBytes : 0;
     if (P.max_bounces >= 0 && P.max_bounces <= 8)
         render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
-            <<<grid, 64, tab + kFoldQueueBytes + tag, stream>>>(P);
-    else
+            <<<grid, 64, tab + kUnitTableBytes + kFoldQueueBytes + tag, stream>>>(P);
+    else  // (PACKL: no near-unit Normalize table, render_tiles_kernel)
         render_tiles_kernel<MathFast, true, 8, uint8_t, 0, 4, true, false, false, SPLIT, true, true, false, true>
             <<<grid, 64, tab + kFoldQueueBytesL + tag, stream>>>(P);
 }
@@ -1078,6 +1079,7 @@ constexpr size_t kStealLdsBytes = 2 * 64 * sizeof(unsigned);  // STEAL: every pi
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
           bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false, bool STEAL = false>
 static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
+    // (`tab`: with the near-unit Normalize table; `tab - kUnitTableBytes`: the any-depth PACKL kernels, which have none)
     const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kShadeConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad() + (SPLIT ? kFoldTagBytes : 0);
     constexpr int DEEP = deep_lds_levels<RecT>();
@@ -1107,7 +1109,7 @@ static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_
     if constexpr (DEFER && sizeof(RecT) == 1) {
         if (P.scene.n < 256) {  // any depth: packed records + pooled stack, deferred fold
             render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
-                <<<grid, 64, tab + kFoldQueueBytesL, stream>>>(P);
+                <<<grid, 64, tab - kUnitTableBytes + kFoldQueueBytesL, stream>>>(P);
             return;
         }
     }

@@ -118,10 +118,11 @@ __device__ __forceinline__ void seq_sqrt_batch(const double (&x)[K], double (&ou
 // The LDS constants of a shading kernel: the 16 sincos constants and the near-unit Normalize table (rtm_device.h); lanes
 // 0 .. 31 of a wave each write their share.  The table's entries are what div3_by_magnitude computes for those squared
 // lengths, instruction for instruction.
+template <bool UNIT = true>
 __device__ __forceinline__ void fill_shade_consts(double* consts, const int lane) {
     if (lane < kTrigConstCount) {
         consts[lane] = TrigFromRegs{}[lane];
-    } else if (lane < kTrigConstCount + kUnitWindow) {
+    } else if (UNIT && lane < kTrigConstCount + kUnitWindow) {
         const int k = lane - kTrigConstCount;
         const double y = (double)sqrtf_fast(__uint_as_float(kUnitWindowFirst + (uint32_t)k));
         consts[kTrigConstCount + 2 * k] = y;
@@ -256,6 +257,11 @@ struct MathSpecT {
     static constexpr bool kGuard = GUARD;
     bool bad = false;
     const double* trig_lds = nullptr;  // LDS copy of the sincos constants (optional)
+    const double* unit_lds = nullptr;  // ... and the near-unit Normalize table (optional): set_lds
+    __device__ __forceinline__ void set_lds(const ShadeLds& l) {
+        trig_lds = l.trig;
+        unit_lds = l.unit;
+    }
     __device__ __forceinline__ double sqrt64(double x) {
         bad = bad || !MathFast::sqrt_fast_ok(x);
         return seq_sqrt(x);
@@ -342,7 +348,7 @@ struct MathSpecT {
     // the table holds what div3_by_magnitude computes (fill_shade_consts).  A length outside the window trips `bad`.
     __device__ __forceinline__ D3 normalize_near_unit(D3 a) {
         if constexpr (GUARD) {
-            if (trig_lds) {
+            if (unit_lds) {
                 const double sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
                 const unsigned k = __float_as_uint((float)(sx + sy + sz)) - kUnitWindowFirst;
 #if RTM_TOL
@@ -354,7 +360,7 @@ struct MathSpecT {
                 lo = hz < lo ? hz : lo;
                 bad = bad | (k >= (unsigned)kUnitWindow) | (lo < 0x0DF00000u);  // see div3_by_magnitude
 #endif
-                const double2 yr = reinterpret_cast<const double2*>(trig_lds + kTrigConstCount)[k & (unsigned)(kUnitWindow - 1)];
+                const double2 yr = reinterpret_cast<const double2*>(unit_lds)[k & (unsigned)(kUnitWindow - 1)];
                 auto one = [&](double x) {
                     return seq_quot(x, yr.x, yr.y);
                 };
@@ -470,6 +476,7 @@ __device__ __forceinline__ double refined_rcp_or_nan(double y) {
 struct MathRefI {
     static constexpr bool bad = false;
     const double* trig_lds = nullptr;
+    __device__ __forceinline__ void set_lds(const ShadeLds& l) { trig_lds = l.trig; }
     __device__ __forceinline__ D3 normalize(D3 a) { return MathRef::div3(a, magnitude(a)); }
     __device__ __forceinline__ D3 normalize_y0(D3 a) { return normalize(a); }
     __device__ __forceinline__ D3 normalize_near_unit(D3 a) { return normalize(a); }
@@ -1568,14 +1575,14 @@ template <class Scene, typename PushFn>
 __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, const double dis, const int mode,
                                                 const int max_bounces, D3& org, D3& dir, int& depth,
                                                 RngStream& rng, D3& term, PathCounters& pc, PushFn push,
-                                                const double* trig_lds = nullptr) {
+                                                const ShadeLds lds = ShadeLds()) {
     ShadeOut o;
     typename std::conditional<Scene::kPlanes, MathSpecZ, MathSpec>::type m;  // plane normals have exact zeros: see MathSpecT
-    m.trig_lds = trig_lds;
+    m.set_lds(lds);
     bool cont = path_shade_core(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
         MathRefI r;
-        r.trig_lds = trig_lds;
+        r.set_lds(lds);
         cont = path_shade_core(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     }
     pc.casts++;
@@ -1602,15 +1609,15 @@ __device__ __forceinline__ bool path_shade_spec(const Scene& sc, const int id, c
 template <class Scene, typename PushFn, typename FixFn>
 __device__ __forceinline__ bool path_shade_spec_fix(const Scene& sc, int& id, double& dis, const int mode, const int max_bounces,
                                                     D3& org, D3& dir, int& depth, RngStream& rng, D3& term, PathCounters& pc,
-                                                    PushFn push, const double* trig_lds, const bool flagged, FixFn fix) {
+                                                    PushFn push, const ShadeLds lds, const bool flagged, FixFn fix) {
     ShadeOut o;
     typename std::conditional<Scene::kPlanes, MathSpecZ, MathSpec>::type m;
-    m.trig_lds = trig_lds;
+    m.set_lds(lds);
     bool cont = path_shade_core(m, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     if (__builtin_amdgcn_ballot_w64(m.bad || flagged) != 0) {
         fix(id, dis);
         MathRefI r;
-        r.trig_lds = trig_lds;
+        r.set_lds(lds);
         cont = path_shade_core(r, sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, o);
     }
     pc.casts++;
@@ -1633,13 +1640,13 @@ __device__ __forceinline__ bool path_shade_spec_fix(const Scene& sc, int& id, do
 template <class M, int UNROLL, class Scene, typename PushFn>
 __device__ __forceinline__ bool path_step(const Scene& sc, const int mode, const int max_bounces,
                                           D3& org, D3& dir, int& depth, RngStream& rng, D3& term,
-                                          PathCounters& pc, PushFn push, const double* trig_lds = nullptr,
+                                          PathCounters& pc, PushFn push, const ShadeLds lds = ShadeLds(),
                                           int* hit_id = nullptr) {
     double dis;
     const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
     if (hit_id) *hit_id = id;
     if constexpr (std::is_same<M, MathFast>::value)
-        return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push, trig_lds);
+        return path_shade_spec(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push, lds);
     else
         return path_shade<M>(sc, id, dis, mode, max_bounces, org, dir, depth, rng, term, pc, push);
 }

@@ -277,7 +277,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
-    double* park = trig + kShadeConstCount;  // the shading constants (sincos, near-unit Normalize)
+    // the shading constants: sincos and — except in the any-depth kernels, which have no LDS to spare — the near-unit Normalize table
+    constexpr bool kUnitTab = !PACKL;
+    double* park = trig + (kUnitTab ? kShadeConstCount : kTrigConstCount);
+    const ShadeLds shade_lds(trig, kUnitTab);
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
     // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
     uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
     if constexpr (DEFER) fq_pend[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
-    fill_shade_consts(trig, lane);
+    fill_shade_consts<kUnitTab>(trig, lane);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
         double pick = v9[0];
@@ -676,11 +679,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             ShadeOut o;
             {
                 MathSpec m;
-                m.trig_lds = trig;
+                m.set_lds(shade_lds);
                 path_bounce_core(m, sc, sid, dis, P.mode, org, dir, rng, o);
                 if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
                     MathRefI r;
-                    r.trig_lds = trig;
+                    r.set_lds(shade_lds);
                     path_bounce_core(r, sc, sid, dis, P.mode, org, dir, rng, o);
                 }
             }
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 double dis;
                 hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
                 const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
-                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig,
+                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
                                            flagged, [&](int& id_fix, double& dis_fix) {
                                                double dis_ref;
                                                const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             } else
 #endif
             cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
-                                        trig, &hit_id);
+                                        shade_lds, &hit_id);
             if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
             // counters (src/Renderer.cpp has none; rtm_stats): one cast per live lane, one draw for the RR test of a
             // hit below the depth cap, two more and a bounce when the path continues
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 double dis;
                 hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
                 const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
-                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig,
+                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
                                            flagged, [&](int& id_fix, double& dis_fix) {
                                                double dis_ref;
                                                const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                            });
             } else
 #endif
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, trig, &hit_id);
+            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds, &hit_id);
             const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_busy;
             unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_busy;
             if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
@@ -1010,10 +1013,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             double dis;
             const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
             ts1 = stamp_now();
-            cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+            cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
             ts2 = stamp_now();
         } else {
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, trig);
+            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
         }
         if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
             cont = false;
