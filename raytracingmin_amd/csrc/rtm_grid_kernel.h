@@ -56,10 +56,11 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     const int lane = threadIdx.x;
     double* cam = reinterpret_cast<double*>(lds_raw);  // 9 camera doubles + pad
     double* trig = cam + 10;                           // the shading constants (sincos, near-unit Normalize)
-    RecT* rec = reinterpret_cast<RecT*>(trig + kShadeConstCount);
+    const bool unit_tab = P.unit_tab != 0u;            // wave-uniform: the launcher found the LDS for the near-unit Normalize table
+    RecT* rec = reinterpret_cast<RecT*>(trig + (unit_tab ? kShadeConstCount : kTrigConstCount));
     unsigned* next_unit = reinterpret_cast<unsigned*>(rec + LDS_D * 64);
     unsigned char* queue = reinterpret_cast<unsigned char*>(next_unit + 4);  // the walks' candidate queue (16-byte aligned)
-    fill_shade_consts(trig, lane);
+    fill_shade_consts(trig, lane, unit_tab);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
         double pick = v9[0];
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
             RTM_GRID_OCC(8);
             if constexpr (COUNT) n_tests += walk.tests;
             D3 term;
-            bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, ShadeLds(trig, true));
+            bool cont = path_shade_spec(sc, walk.best, walk.dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, ShadeLds(trig, unit_tab));
             if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
                 cont = false;
                 term = d3(0, 0, 0);

@@ -1060,65 +1060,80 @@ static size_t debug_lds_pad() {
     return pad;
 }
 
-constexpr size_t kUnitTableBytes = (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);  // rtm_device.h: the near-unit Normalize table
 // Scenes that hold planes (render_view: up to kLdsTableMaxSpheres objects): the deferred-fold kernels with the object
 // chunk, packed records for a depth cap of at most 8 (PACK8), by position for any depth (PACKL)
+constexpr size_t kUnitTableBytes = (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);  // rtm_device.h: the near-unit Normalize table
+// The launch's LDS with the near-unit Normalize table where it does not cost a wave per CU (P.unit_tab tells the kernel)
+static size_t with_unit_table(RenderParams& P, size_t lds) {
+    P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
+    return lds + (P.unit_tab ? kUnitTableBytes : 0);
+}
 template <bool SPLIT>
-static void launch_render_planes(const RenderParams& P, unsigned grid, hipStream_t stream) {
+static void launch_render_planes(const RenderParams& P_in, unsigned grid, hipStream_t stream) {
+    RenderParams P = P_in;
     const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
     constexpr size_t tag = SPLIT ? kFoldTagBytes : 0;
-    if (P.max_bounces >= 0 && P.max_bounces <= 8)
+    if (P.max_bounces >= 0 && P.max_bounces <= 8) {
+        const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + tag);
         render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
-            <<<grid, 64, tab + kUnitTableBytes + kFoldQueueBytes + tag, stream>>>(P);
-    else  // (PACKL: no near-unit Normalize table, render_tiles_kernel)
+            <<<grid, 64, lds, stream>>>(P);
+    } else {
+        const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL + tag);
         render_tiles_kernel<MathFast, true, 8, uint8_t, 0, 4, true, false, false, SPLIT, true, true, false, true>
-            <<<grid, 64, tab + kFoldQueueBytesL + tag, stream>>>(P);
+            <<<grid, 64, lds, stream>>>(P);
+    }
 }
 
 constexpr size_t kStealLdsBytes = 2 * 64 * sizeof(unsigned);  // STEAL: every pixel's next own sample and own-sample end
 template <class M, bool LDS_TAB, int UNROLL, typename RecT, int WPE = 1, bool PARK = false, bool STAMP = false,
           bool TRY_PACK8 = false, bool SPLIT = false, bool DEFER = false, bool STEAL = false>
-static void launch_render_depth(const RenderParams& P, unsigned grid, hipStream_t stream) {
-    // (`tab`: with the near-unit Normalize table; `tab - kUnitTableBytes`: the any-depth PACKL kernels, which have none)
-    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kShadeConstCount) * sizeof(double) +
+static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStream_t stream) {
+    RenderParams P = P_in;  // (unit_tab: the near-unit Normalize table where the launch's LDS has the room, with_unit_table)
+    const size_t tab = (LDS_TAB ? lds_table_bytes(P.scene.n) : 0) + (10 + kTrigConstCount) * sizeof(double) +
                        (PARK ? 6 * 64 * sizeof(double) : 0) + debug_lds_pad() + (SPLIT ? kFoldTagBytes : 0);
     constexpr int DEEP = deep_lds_levels<RecT>();
     if constexpr (TRY_PACK8 && sizeof(RecT) == 1) {
         if (P.max_bounces >= 0 && P.max_bounces <= 8 && P.scene.n < 256) {  // ids and the identity index in a byte
             if constexpr (DEFER && UNROLL == -8) {
                 // scenes under 8 spheres (every shipped scene): the instantiation for exactly n spheres
+                const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
                 switch (P.scene.n) {
 #define RTM_EXACT_N(k)                                                                                     \
     case k:                                                                                                \
         render_tiles_kernel<M, LDS_TAB, -100 - k, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL> \
-            <<<grid, 64, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0), stream>>>(P);               \
+            <<<grid, 64, lds, stream>>>(P);                                                                \
         return;
                     RTM_EXACT_N(1) RTM_EXACT_N(2) RTM_EXACT_N(3) RTM_EXACT_N(4) RTM_EXACT_N(5) RTM_EXACT_N(6) RTM_EXACT_N(7)
 #undef RTM_EXACT_N
                     default: break;
                 }
             }
-            if constexpr (DEFER)
+            if constexpr (DEFER) {
+                const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL>
-                    <<<grid, 64, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0), stream>>>(P);
-            else
-                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, false><<<grid, 64, tab, stream>>>(P);  // (never split: the split rides on the fold queue)
+                    <<<grid, 64, lds, stream>>>(P);
+            } else {
+                const size_t lds = with_unit_table(P, tab);
+                render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, false><<<grid, 64, lds, stream>>>(P);  // (never split: the split rides on the fold queue)
+            }
             return;
         }
     }
     if constexpr (DEFER && sizeof(RecT) == 1) {
         if (P.scene.n < 256) {  // any depth: packed records + pooled stack, deferred fold
+            const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL);  // (10 072 bytes for a 7-sphere scene: no room)
             render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
-                <<<grid, 64, tab - kUnitTableBytes + kFoldQueueBytesL, stream>>>(P);
+                <<<grid, 64, lds, stream>>>(P);
             return;
         }
     }
-    if (!needs_pool(P))
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, false, false>
-            <<<grid, 64, tab + 16 * 64 * sizeof(RecT), stream>>>(P);
-    else
-        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP, false, false>
-            <<<grid, 64, tab + DEEP * 64 * sizeof(RecT), stream>>>(P);
+    if (!needs_pool(P)) {
+        const size_t lds = with_unit_table(P, tab + 16 * 64 * sizeof(RecT));
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, false, false><<<grid, 64, lds, stream>>>(P);
+    } else {
+        const size_t lds = with_unit_table(P, tab + DEEP * 64 * sizeof(RecT));
+        render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, DEEP, WPE, PARK, STAMP, false, false><<<grid, 64, lds, stream>>>(P);
+    }
 }
 
 // `variant` is resolved (render_view): one of ref, fast-lds, fast-global, stamped, global-defer, primary-reuse, fp32.
@@ -1179,14 +1194,15 @@ static void launch_render(int variant, const RenderParams& P, unsigned grid, hip
             return;
         }
         case kVariantPrimaryReuse: {  // validated by render_view: 1 <= n <= 24, 0 <= max_bounces <= 8
-            const size_t lds = lds_table_bytes(n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                               kFoldQueueBytes + debug_lds_pad();
+            RenderParams Q = P;
+            const size_t lds = with_unit_table(Q, lds_table_bytes(n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                                                      kFoldQueueBytes + debug_lds_pad());
             if (n < 8)
                 render_tiles_kernel<MathFast, true, -8, uint8_t, 16, 4, true, false, true, false, true, false, true>
-                    <<<grid, 64, lds, stream>>>(P);
+                    <<<grid, 64, lds, stream>>>(Q);
             else
                 render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, false, true, false, true>
-                    <<<grid, 64, lds, stream>>>(P);
+                    <<<grid, 64, lds, stream>>>(Q);
             return;
         }
         case kVariantStamped:  // render_view: n <= kLdsTableMaxSpheres
@@ -1997,8 +2013,10 @@ static int run_grid(RenderParams& P, unsigned tiles, StreamCtx& ctx, const Rende
     P.nz_bits = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(ws) + chunk * grid_tile_term_bytes(P.total_samples));
     const bool deep = needs_pool(P);
     const bool planes = P.scene.plane != nullptr;
-    const size_t lds = (10 + kShadeConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
-                       GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
+    size_t lds = (10 + kTrigConstCount) * sizeof(double) + (size_t)(deep ? 32 : 16) * 64 * sizeof(uint32_t) + 16 +
+                 GridWalk<MathFast, SceneGlobal>::queue_bytes(64) + debug_lds_pad();
+    P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
+    if (P.unit_tab) lds += kUnitTableBytes;
     for (unsigned base = 0; base < tiles; base += (unsigned)chunk) {
         const unsigned cnt = (unsigned)std::min<size_t>(chunk, tiles - base);
         P.xcd_on = xcd_off ? 0u : 1u;

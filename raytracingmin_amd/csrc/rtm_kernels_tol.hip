@@ -29,9 +29,13 @@
 namespace rtm_tol {
 
 template <int UNROLL, bool SPLIT>
-static void launch_one(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
-    const size_t lds = lds_table_bytes(P.scene.n) + (10 + kShadeConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                       kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) /* prim_mask */ + lds_pad;
+static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, hipStream_t stream) {
+    RenderParams P = P_in;
+    size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                 kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) /* prim_mask */ + lds_pad;
+    // the near-unit Normalize table (rtm_device.h) where its 256 bytes do not cost a wave per CU
+    P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
+    if (P.unit_tab) lds += (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);
     // <M, LDS_TAB, UNROLL, RecT, LDS_D, WPE, PARK, STAMP, PACK8, SPLIT, DEFER, PACKL, REUSE, PLANES, STEAL>
     render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, false, true>
         <<<grid, 64, lds, stream>>>(P);

@@ -118,11 +118,10 @@ __device__ __forceinline__ void seq_sqrt_batch(const double (&x)[K], double (&ou
 // The LDS constants of a shading kernel: the 16 sincos constants and the near-unit Normalize table (rtm_device.h); lanes
 // 0 .. 31 of a wave each write their share.  The table's entries are what div3_by_magnitude computes for those squared
 // lengths, instruction for instruction.
-template <bool UNIT = true>
-__device__ __forceinline__ void fill_shade_consts(double* consts, const int lane) {
+__device__ __forceinline__ void fill_shade_consts(double* consts, const int lane, const bool unit_table) {
     if (lane < kTrigConstCount) {
         consts[lane] = TrigFromRegs{}[lane];
-    } else if (UNIT && lane < kTrigConstCount + kUnitWindow) {
+    } else if (unit_table && lane < kTrigConstCount + kUnitWindow) {
         const int k = lane - kTrigConstCount;
         const double y = (double)sqrtf_fast(__uint_as_float(kUnitWindowFirst + (uint32_t)k));
         consts[kTrigConstCount + 2 * k] = y;

@@ -54,6 +54,9 @@ struct RenderParams {
     // b of a launch renders its tile (b % 8) * xcd_q + min(b % 8, xcd_rem) + b / 8, so that an XCD's blocks cover one
     // contiguous part of the frame and its L2 holds that part's cells (xcd_q = tiles / 8, xcd_rem = tiles % 8)
     unsigned xcd_on, xcd_q, xcd_rem;
+    // the launch's LDS holds the near-unit Normalize table behind the sincos constants (rtm_device.h; set by the launcher
+    // where the 256 bytes do not cost a wave per CU: unit_table_fits)
+    unsigned unit_tab;
     // the tolerance translation unit (RTM_TOL): per tile of the launch 64 words — bit s of word p: "sub-pixel s of pixel p
     // has a primary ray whose nearest hit last-bit differences could change" (prim_prepass_kernel); null elsewhere
     const unsigned long long* __restrict__ prim_masks;
@@ -124,6 +127,12 @@ struct RecordStack {
 // LDS copy of the scene tables: n geometry rows (4 doubles) + n+1 material rows (8 doubles, the last
 // one is the identity row) + n normal-length rows (3 doubles: |hit - centre| as Magnitude returns it, its refined
 // reciprocal, and the float r*r in the low word of the third)
+// Does a launch whose workgroups (one wave each) take `lds` bytes keep its waves per CU with the near-unit Normalize table's
+// 256 bytes on top?  160 KB of LDS per CU, at most 16 waves (4 per SIMD at the kernels' 128 registers).
+inline bool unit_table_fits(size_t lds) {
+    auto waves = [](size_t b) { const size_t w = b ? (size_t)163840 / b : 16; return w > 16 ? (size_t)16 : w; };
+    return waves(lds) == waves(lds + (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double));
+}
 __host__ __device__ inline size_t lds_table_bytes(int n) { return ((size_t)n * 7 + ((size_t)n + 1) * 8) * sizeof(double); }
 
 // src/Renderer.cpp:227-232; sx, sy in 1..SS
@@ -277,10 +286,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
-    // the shading constants: sincos and — except in the any-depth kernels, which have no LDS to spare — the near-unit Normalize table
-    constexpr bool kUnitTab = !PACKL;
-    double* park = trig + (kUnitTab ? kShadeConstCount : kTrigConstCount);
-    const ShadeLds shade_lds(trig, kUnitTab);
+    // the shading constants: sincos and — where the launcher found the LDS for it — the near-unit Normalize table
+    const bool unit_tab = P.unit_tab != 0u;  // wave-uniform
+    double* park = trig + (unit_tab ? kShadeConstCount : kTrigConstCount);
+    const ShadeLds shade_lds(trig, unit_tab);
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
     // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
     uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
     if constexpr (DEFER) fq_pend[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
-    fill_shade_consts<kUnitTab>(trig, lane);
+    fill_shade_consts(trig, lane, unit_tab);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
         double pick = v9[0];
