@@ -117,7 +117,7 @@ def measured_fp64_peak(rtm):
 KERNEL_OF_VARIANT = {1: "render_tiles_kernel (per-object loop, compiler math)", 2: "render_tiles_kernel", 3: "render_tiles_kernel",
                      7: "render_tiles_kernel (stamped)", 9: "render_tiles_kernel", 12: "wf_nearest_f32_kernel + wf_shade_kernel",
                      14: "render_tiles_kernel", 15: "render_tiles_kernel (primary-hit reuse)", 16: "render_fp32_kernel",
-                     17: "render_grid_kernel + grid_finalize_kernel", 18: "rtm_tol::render_tiles_kernel (+ prim_mask_kernel)"}
+                     17: "render_grid_kernel + grid_finalize_kernel", 18: "rtm_tol::render_tiles_kernel (+ prim_prepass_kernel)"}
 
 
 def roofline_of(st, kernel_ms, n_objects, width, d4_fraction=None, peak_measured=None, replay=None):
