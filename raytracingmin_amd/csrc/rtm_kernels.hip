@@ -113,6 +113,20 @@ static void flatten_scene(const rtm_sphere* sp, size_t n, std::vector<double>& g
     }
 }
 
+// SceneView::axis_pat from flattened geometry rows (cx, cy, cz, r*r): 1 / 2 / 3 where x / y / z is the centre's only
+// coordinate that is not +-0 (all finite), else 0; a plane's row (negative "r*r") is 0.
+static uint64_t axis_pattern(const double* geom, size_t n) {
+    uint64_t pat = 0;
+    for (size_t i = 0; i < n && i < 32; ++i) {
+        const double* g = geom + i * 4;
+        if (!(std::isfinite(g[0]) && std::isfinite(g[1]) && std::isfinite(g[2])) || !(g[3] >= 0.0)) continue;
+        const bool zx = g[0] == 0.0, zy = g[1] == 0.0, zz = g[2] == 0.0;
+        const uint64_t a = (!zx && zy && zz) ? 1u : (zx && !zy && zz) ? 2u : (zx && zy && !zz) ? 3u : 0u;
+        pat |= a << (2 * i);
+    }
+    return pat;
+}
+
 __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n,
                                      double* __restrict__ geom, double* __restrict__ mat, double* __restrict__ surf = nullptr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,6 +275,7 @@ struct rtm_scene {
     rtm::GridHeader grid_hdr;           // host copy (grid_for: is the camera within the pads' reach?)
     bool grid_far_bounces = false;      // a diffuse sphere encloses the gridded ones from beyond the pads' reach (build_scene_grid)
     bool has_planes = false;
+    uint64_t axis_pat = 0;              // SceneView::axis_pat: which of the first 32 spheres sit on a coordinate axis (axis_pattern)
     uint64_t content_hash = 0;            // cache entries only ...
     std::vector<unsigned char> content;   // ... and the bytes the hash was taken of (compared on a hash hit)
     // Streams that have rendered from this scene, one event each, re-recorded behind every render that names the scene:
@@ -294,8 +309,10 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
     return RTM_OK;
 }
 static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n,
-                            const double* plane = nullptr, const void* grid = nullptr, const double* surf = nullptr) {
+                            const double* plane = nullptr, const void* grid = nullptr, const double* surf = nullptr,
+                            uint64_t axis_pat = 0) {
     SceneView v{(const double4*)geom, mat, (int)n};
+    v.axis_pat = axis_pat;
     v.plane = plane;
     v.surf = surf;
     v.grid = static_cast<const GridHeader*>(grid);
@@ -596,6 +613,7 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     sc.n = n;
     std::vector<double> hg, hm, hs;
     flatten_scene(sp, n, hg, hm, &hs);
+    sc.axis_pat = axis_pattern(hg.data(), n);
     int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
@@ -624,6 +642,11 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
     rc = launch_scene_aux(sc.geom.as<double>(), n, sc.aux.as<double>(), nullptr);
     if (rc != RTM_OK) return rc;
     RTM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (n > 0 && n <= 32) {  // a small scene's rows come back for SceneView::axis_pat (1 KB)
+        std::vector<double> rows(n * 4);
+        RTM_HIP_CHECK(hipMemcpy(rows.data(), sc.geom.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+        sc.axis_pat = axis_pattern(rows.data(), n);
+    }
     if (n < kGridMinSpheres) return RTM_OK;
     std::vector<double> hg(n * 4);  // the grid is built on the host: the geometry rows come back once
     RTM_HIP_CHECK(hipMemcpy(hg.data(), sc.geom.p, hg.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -698,6 +721,7 @@ int scene_create_objects(const rtm_object* objs, size_t n, int device, rtm_scene
         if ((rc = sc->plane.alloc_pooled(rows.size() * sizeof(double), device)) != RTM_OK) return rc;
         RTM_HIP_CHECK(hipMemcpy(sc->plane.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
         sc->has_planes = true;
+        sc->axis_pat = 0;  // (the object kernels do not read it; a plane's position row is not a sphere's centre)
         // the grid of a scene with planes: over its spheres, the planes among the objects every ray tests (build_scene_grid)
         std::vector<double> hm((n + 1) * 8);
         RTM_HIP_CHECK(hipMemcpy(hm.data(), sc->mat.p, hm.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1097,6 +1121,13 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
             if constexpr (DEFER && UNROLL == -8) {
                 // scenes under 8 spheres (every shipped scene): the instantiation for exactly n spheres
                 const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
+#if RTM_OPT_AXIS
+                if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (rtm_path.h: sphere_disc)
+                    render_tiles_kernel<M, LDS_TAB, axis_unroll(7, kAxisSigCornell7), RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL>
+                        <<<grid, 64, lds, stream>>>(P);
+                    return;
+                }
+#endif
                 switch (P.scene.n) {
 #define RTM_EXACT_N(k)                                                                                     \
     case k:                                                                                                \
@@ -2227,7 +2258,7 @@ int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_opti
     RenderParams P;
     RenderPlan plan;
     const SceneView view = scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>());
+                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat);
     for (int k = 0; k < 6; ++k) out[k] = 0;
     if (output_rows(opt) == 0) return RTM_OK;
     rc = plan_render(st, view, scene->n, opt, P, plan);
@@ -2257,7 +2288,7 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
     std::shared_lock<std::shared_mutex> gate(g_gate);
     reap_scenes(false);
     rc = render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>()),
+                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat),
                      scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
     note_scene_use(scene, (hipStream_t)stream_v);  // also after a failure: part of the work may have been queued
     return rc;
@@ -2275,7 +2306,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_scene(sp, n, opt->device, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>()),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
         return rc;
@@ -2289,7 +2320,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_device_scene(sp, n, opt->device, stream, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>()),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);
         return rc;

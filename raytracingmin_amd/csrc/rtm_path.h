@@ -21,6 +21,10 @@
 #define RTM_OPT_ONB RTM_OPT_GUARD  // rides on the guards' "no zero component" guarantee
 #endif
 
+#ifndef RTM_OPT_AXIS
+#define RTM_OPT_AXIS 1  // axis-signature instantiations of the exact-n kernels (sphere_disc; A/B switch)
+#endif
+
 #include "../../include/rtm.h"
 #include "rtm_device.h"
 
@@ -556,6 +560,11 @@ struct SceneView {
     // png::SurfaeSample (rtm_surface.h) reads what PathTracing does not: per object the RAW material colour (3 doubles) and
     // the radius as the float it is, widened (SphereObject::ComputeSurfacePoint); null where the tables were made without
     const double* __restrict__ surf = nullptr;
+    // two bits per sphere for the first 32 (sphere i: bits 2i, 2i+1; set by the host where it holds the geometry, else 0):
+    // 1 / 2 / 3 = the centre's only non-zero coordinate is x / y / z (the other two are +-0), 0 = anything else.  The
+    // chunked search of the LDS-table kernels evaluates such a sphere's discriminant from per-ray shared products
+    // (sphere_disc below): the reference's own roundings, fewer instructions.
+    unsigned long long axis_pat = 0ull;
 };
 
 // png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line
@@ -762,6 +771,76 @@ __device__ __forceinline__ void accept_update(const double b, const double sq, c
 #endif
 }
 
+// Discriminants of spheres whose centre lies ON A COORDINATE AXIS (SceneView::axis_pat; the six walls and the light of the
+// shipped Cornell box, every sphere of simpleSetting1.json): with c = (cx, 0, 0) the reference's p_o = c - org is
+// (cx - ox, -oy, -oz) exactly, its products with dir are -(oy dy), -(oz dz) exactly and their squares oy oy, oz oz, so
+//   b  = ((px dx) + (py dy)) + (pz dz) = ((px dx) - oy dy) - oz dz           (src/SettingData.cpp:199, src/Ray.h Dot)
+//   pp = ((px px) + (py py)) + (pz pz) = ((px px) + oy oy) + oz oz           (:200)
+// with every rounding where the reference has it — the per-ray products o_k d_k, o_k o_k are shared by all such spheres of
+// the scene.  Likewise (0, cy, 0): b = ((py dy) - ox dx) - oz dz (the first sum commutes), pp = (ox ox + py py) + oz oz; and
+// (0, 0, cz): b = (pz dz) - (ox dx + oy dy) since (-a) + (-b) = -(a + b) in round-to-nearest, pp = (ox ox + oy oy) + pz pz.
+// The only bits that can differ are the SIGNS OF ZEROS (0 - (+0) = +0 where -(+0) = -0): a zero product changes no sum it
+// is added to unless the sum is zero itself; b = +-0 gives the same b b, t1, t2 up to a zero's sign, and a zero t is
+// rejected by t < 1e-5f either way.  16 instructions -> 10 (x, y) / 8 (z) without contraction.
+// The tolerance unit (RTM_TOL) also shares the SUMS of the two foreign products (one rounding placed differently, the same
+// error size as the contraction it already has): 11 -> 5.
+struct AxisShared {
+#if RTM_TOL
+    double Pyz, Pxz, Pxy, Qyz, Qxz, Qxy;
+#else
+    double Px, Py, Pz, Pxy, Qx, Qy, Qz, Qxy;
+#endif
+    __device__ __forceinline__ AxisShared(const D3 org, const D3 dir) {
+        const double px = org.x * dir.x, py = org.y * dir.y, pz = org.z * dir.z;
+        const double qx = org.x * org.x, qy = org.y * org.y, qz = org.z * org.z;
+#if RTM_TOL
+        Pyz = py + pz; Pxz = px + pz; Pxy = px + py;
+        Qyz = qy + qz; Qxz = qx + qz; Qxy = qx + qy;
+#else
+        Px = px; Py = py; Pz = pz; Pxy = px + py;
+        Qx = qx; Qy = qy; Qz = qz; Qxy = qx + qy;
+#endif
+    }
+};
+// Axis signatures that have an instantiation of the exact-n kernels (nearest_hit: UNROLL <= -1000; the launchers compare
+// SceneView::axis_pat and the sphere count): ExampleScene/cornellBoxSetting.json — the light on the y axis and the six wall
+// spheres on +x, -x, +y, -y, +z, -z (BASELINE configs[1..3]).  A run-time pattern per sphere (a scalar branch in front of
+// every discriminant) was measured first and lost: 130.8 -> 139.4 ms for the tolerance row, 160.8 -> 161.6 ms for the exact
+// kernel (profiles/r4/axis_ab.txt) — the patterns' SGPRs spill to VGPR lanes and the chunk stops being one basic block.
+constexpr unsigned kAxisSigCornell7 = 2u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12);
+constexpr int axis_unroll(const int n, const unsigned sig) { return -(1000 + n + 8 * (int)sig); }
+// b and D4 of sphere g (src/SettingData.cpp:198-200); pat: 0 general, 1 / 2 / 3 the centre is on the x / y / z axis
+__device__ __forceinline__ void sphere_disc(const double4 g, const unsigned pat, const D3 org, const D3 dir,
+                                            const AxisShared& A, double& b, double& D4) {
+    if (pat == 1u) {
+        const double px = g.x - org.x;
+#if RTM_TOL
+        b = px * dir.x - A.Pyz;
+        D4 = b * b - (px * px + A.Qyz) + g.w;
+#else
+        b = px * dir.x - A.Py - A.Pz;
+        D4 = b * b - (px * px + A.Qy + A.Qz) + g.w;
+#endif
+    } else if (pat == 2u) {
+        const double py = g.y - org.y;
+#if RTM_TOL
+        b = py * dir.y - A.Pxz;
+        D4 = b * b - (py * py + A.Qxz) + g.w;
+#else
+        b = py * dir.y - A.Px - A.Pz;
+        D4 = b * b - (A.Qx + py * py + A.Qz) + g.w;
+#endif
+    } else if (pat == 3u) {
+        const double pz = g.z - org.z;
+        b = pz * dir.z - A.Pxy;
+        D4 = b * b - (A.Qxy + pz * pz) + g.w;
+    } else {
+        const D3 p_o = d3(g.x - org.x, g.y - org.y, g.z - org.z);  // src/SettingData.cpp:198
+        b = dot(p_o, dir);                                          // :199
+        D4 = b * b - dot(p_o, p_o) + g.w;                           // :200
+    }
+}
+
 // K consecutive spheres starting at i0 as ONE basic block: K independent Intersect evaluations
 // (independent dependency chains the scheduler interleaves), their square roots behind a single
 // wave-uniform guard, then the K acceptance updates in index order (strict <: the lowest index still
@@ -807,9 +886,10 @@ __device__ __forceinline__ void sphere_chunk_g(const double4 (&g)[K], const int 
 // spheres whose geometry is fetched together inside a chunk (profiles/r1: 7 at once 202.7 ms, 4: 195.6,
 // 3: 194.5, 2: 194.2 ms on the same box; SGPR spills 44 -> 10)
 constexpr int kGeomPhase = 2;
-template <class M, int K, class Scene, bool EARLY_OUT = false>
+template <class M, int K, class Scene, bool EARLY_OUT = false, unsigned SIG = 0u>
 __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, const D3 org, const D3 dir,
                                              double& dis, int& hit_object) {
+    static_assert(SIG == 0u || (K > kGeomPhase && K < 8 && !EARLY_OUT), "an axis signature names the spheres of ONE exact chunk");
     constexpr int PH = kGeomPhase;
     if constexpr (K > PH && !EARLY_OUT) {
         // The geometry of a chunk arrives by scalar loads, 8 SGPRs per sphere; fetching all K spheres at
@@ -817,6 +897,24 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
         // scalars to VGPR lanes (v_writelane / v_readlane in the hot loop).  Phases of PH spheres keep
         // the batch structure of the rest (K independent chains into ONE sqrt guard and K selects).
         double b[K], D4[K], sq[K];
+        if constexpr (SIG != 0u) {  // the scene's axis signature is a compile-time constant: sphere_disc's branches fold
+            const AxisShared A(org, dir);
+#pragma unroll
+            for (int k0 = 0; k0 < K; k0 += PH) {
+                double4 g[PH];
+#pragma unroll
+                for (int k = 0; k < PH; ++k)
+                    if (k0 + k < K) g[k] = sc.geom_uniform(i0 + k0 + k);
+#pragma unroll
+                for (int k = 0; k < PH; ++k)
+                    if (k0 + k < K) sphere_disc(g[k], (SIG >> (2 * (k0 + k))) & 3u, org, dir, A, b[k0 + k], D4[k0 + k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            M::template sqrt64_batch_hit<K>(D4, sq);
+#pragma unroll
+            for (int k = 0; k < K; ++k) accept_update(b[k], sq[k], i0 + k, dis, hit_object);
+            return;
+        }
 #pragma unroll
         for (int k0 = 0; k0 < K; k0 += PH) {
             double4 g[PH];
@@ -1279,13 +1377,20 @@ __device__ __forceinline__ int nearest_hit(const Scene& sc, const D3 org, const 
             }
             return hit_object;
         }
+        if constexpr (UNROLL <= -1000) {
+            // the caller guarantees n == code & 7 and SceneView::axis_pat == code >> 3 (code = -UNROLL - 1000): one exact
+            // chunk whose spheres' axis patterns are compile-time constants (sphere_disc; the launcher picks it)
+            constexpr int code = -UNROLL - 1000;
+            sphere_chunk<M, (code & 7), Scene, false, (unsigned)(code >> 3)>(sc, 0, org, dir, dis, hit_object);
+            return hit_object;
+        }
         if constexpr (UNROLL <= -101 && UNROLL >= -107) {
             // the caller guarantees n == -UNROLL - 100: the scene is ONE exact chunk, no switch, no other sizes
             // compiled in (scenes under 8 spheres; the launcher picks the instantiation)
             sphere_chunk<M, -UNROLL - 100>(sc, 0, org, dir, dis, hit_object);
             return hit_object;
         }
-        constexpr int U = UNROLL <= -101 ? 8 : (UNROLL < 0 ? -UNROLL : UNROLL);
+        constexpr int U = UNROLL <= -101 ? 8 : (UNROLL < 0 ? -UNROLL : UNROLL);  // (UNROLL <= -1000 returned above)
         static_assert(U == 8 || U == 4, "chunks of 8 or 4 plus an exact tail");
         int i0 = 0;
         if constexpr (UNROLL > 0) {
