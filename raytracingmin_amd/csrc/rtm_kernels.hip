@@ -1153,6 +1153,15 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
     if constexpr (DEFER && sizeof(RecT) == 1) {
         if (P.scene.n < 256) {  // any depth: packed records + pooled stack, deferred fold
             const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL);  // (10 072 bytes for a 7-sphere scene: no room)
+#if RTM_OPT_AXIS
+            if constexpr (UNROLL == -8) {
+                if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (rtm_path.h: sphere_disc)
+                    render_tiles_kernel<M, LDS_TAB, axis_unroll(7, kAxisSigCornell7), RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
+                        <<<grid, 64, lds, stream>>>(P);
+                    return;
+                }
+            }
+#endif
             render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
                 <<<grid, 64, lds, stream>>>(P);
             return;

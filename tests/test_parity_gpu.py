@@ -622,6 +622,63 @@ def test_edge_case_scenes_vs_oracle(rtm, oracle, name):
             assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"]), (name, mode, mb, v)
 
 
+def _axis_room(rtm, light, walls, zero=0.0):
+    """Seven spheres with the shipped Cornell box's AXIS SIGNATURE (light on y; walls on +x -x +y -y +z -z), other numbers."""
+    ly, lr = light
+    objs = [_mk(rtm, (zero, ly, zero), lr, (0, 0, 0), (4, 3.5, 3))]
+    cols = [(.8, .3, .3), (.3, .8, .3), (.3, .3, .8), (.7, .7, .7), (.8, .3, .8), (.3, .8, .8)]
+    for k, (c, r) in enumerate(walls):
+        pos = [zero, zero, zero]
+        pos[k // 2] = c
+        objs.append(_mk(rtm, tuple(pos), r, cols[k], (0, 0, 0)))
+    return objs
+
+
+AXIS_ROOMS = {
+    # a smaller room, walls of different radii, an off-axis camera: every shared product is a generic number
+    "small-room": lambda rtm: (_axis_room(rtm, (6.0, 2.5), [(1005.5, 1000), (-806.25, 800), (507, 500), (-1204, 1200), (2008, 2000), (-307, 300)]),
+                               (0.75, -1.25, -4.0)),
+    # centres written with NEGATIVE zeros, the camera on the z axis (ox = oy = 0: the shared products are signed zeros)
+    "negative-zeros": lambda rtm: (_axis_room(rtm, (9.0, 4.0), [(108, 100), (-108, 100), (108, 100), (-108, 100), (108, 100), (-108, 100)], zero=-0.0),
+                                   (0.0, 0.0, -7.0)),
+    # small spheres on the axes in open space (rays miss; some start inside the light)
+    "open-space": lambda rtm: (_axis_room(rtm, (0.5, 3.0), [(4, 1.5), (-4, 1.0), (5, 2.0), (-3.5, 1.0), (6, 2.5), (-9, 0.5)]),
+                               (0.0, 0.5, -2.0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(AXIS_ROOMS))
+def test_axis_signature_scenes_vs_oracle(rtm, oracle, name):
+    """Scenes that get the axis-signature instantiation of the exact-n kernels (rtm_path.h: sphere_disc — discriminants of
+    spheres whose centre sits on a coordinate axis, from per-ray shared products): image, counters, every depth setting the
+    instantiation exists for (cap <= 8: packed records; any depth: PACKL), against the oracle and the per-object loop."""
+    objs, origin = AXIS_ROOMS[name](rtm)
+    cam = rtm.Camera(rtm.vec3(*origin), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.6)
+    data = rtm.SettingData(width=56, height=40, samples=4, superSamples=2, camera=cam, object=objs)
+    ost, oarr, n = _oracle_view(oracle, data)
+    for mode, mb in (("repaired", 8), ("repaired", -1), ("repaired", 3), ("repaired", 12), ("literal", -1)):
+        m = oracle.MODE_REPAIRED if mode == "repaired" else oracle.MODE_LITERAL
+        ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=m, max_bounces=mb, seed=23, height=40))
+        for v in (0, 2, 9, 1):
+            out, stats = _gpu_image(rtm, data, mode, mb, 23, want=("f64",), variant=v)
+            assert np.array_equal(out["f64"], ref, equal_nan=True), (name, mode, mb, v)
+            assert (stats["casts"], stats["draws"]) == (cnt["casts"], cnt["draws"]), (name, mode, mb, v)
+
+
+def test_axis_signature_near_misses_take_the_general_kernel(rtm, oracle):
+    """One coordinate a denormal instead of zero, or the spheres in another order: not the signature — same answers."""
+    base = rtm.LoadData(oracle.scene_path("cornellBoxSetting.json")).data
+    objs = list(base.object)
+    tiny = _mk(rtm, (5e-324, 10, 0), 5, (0, 0, 0), (5, 5, 5))
+    for variant_objs in ([tiny] + objs[1:], objs[1:] + objs[:1], objs[:6]):
+        data = rtm.SettingData(width=40, height=24, samples=4, superSamples=2, camera=base.camera, object=variant_objs)
+        ost, oarr, n = _oracle_view(oracle, data)
+        for mb in (8, -1):
+            ref, cnt = oracle.render(ost, oarr, n, oracle.make_options(mode=1, max_bounces=mb, seed=3, height=24))
+            out, stats = _gpu_image(rtm, data, "repaired", mb, 3, want=("f64",))
+            assert np.array_equal(out["f64"], ref) and stats["casts"] == cnt["casts"]
+
+
 def test_degenerate_camera_gives_the_same_nans(rtm, oracle):
     """upVec parallel to the view direction: Cross(direction, up) = 0, its Normalize is 0/0 and every
     primary ray is NaN (src/Renderer.cpp:203).  The reference then renders black (NaN rays miss); so
