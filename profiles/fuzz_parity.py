@@ -9,7 +9,8 @@ pipeline) instead of the blocking one.  Round 4: plane scenes up to 1 000 object
 every ray tests: variants 0 and 17), every eleventh case through the other integrator (png::SurfaeSample,
 RTM_MODE_SURFACE_SAMPLE), and — where it serves the scene — every third eligible case through the fp64 TOLERANCE row
 (variant 18), which is judged by north_star's bar (max per-pixel |delta| <= 1e-4) and counted apart, with the number of
-frames that differ at all.  Results: profiles/r1/ .. r4/fuzz_parity.txt."""
+frames that differ at all; seven-sphere rooms with the Cornell box's axis signature and random numbers (the axis-signature
+instantiation of the exact-n kernels, both translation units).  Results: profiles/r1/ .. r4/fuzz_parity.txt."""
 import os
 import sys
 
@@ -32,7 +33,7 @@ def sphere(pos, r, col):
 bad = 0
 tol_cases = tol_out = tol_differ = 0
 for case in range(cases):
-    n = int(rng.choice([1, 2, 5, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
+    n = int(rng.choice([1, 2, 5, 7, 7, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
                         513, 1000, 2500]))
     kind = case % 4
     if kind == 3:  # planes and spheres mixed, in a room
@@ -57,6 +58,20 @@ for case in range(cases):
         objs.append(rtm.SphereObject(rtm.vec3(0, 0, 0), 25.0, rtm.Material(rtm.vec3(0.7, 0.7, 0.7), rtm.vec3(0.3, 0.3, 0.3))))
         n = len(objs)
         cam = rtm.Camera(rtm.vec3(0, 0, -11), rtm.vec3(0, 0, 0), rtm.vec3(0, 1, 0), 1.2)
+        data = rtm.SettingData(width=8, height=8, samples=1, superSamples=1, camera=cam, object=objs)
+    elif kind == 0 and n == 7 and case % 8 != 0:
+        # the shipped Cornell box's AXIS SIGNATURE (light on y, walls on +x -x +y -y +z -z) with other numbers: the scenes of the
+        # axis-signature instantiation of the exact-n kernels (rtm_path.h: sphere_disc), camera anywhere in the room
+        half = float(rng.uniform(3, 12))
+        objs = [rtm.SphereObject(rtm.vec3(0, float(rng.uniform(0.3, 1.0)) * half, 0), float(rng.uniform(0.1, 0.5)) * half,
+                                 rtm.Material(rtm.vec3(0, 0, 0), rtm.vec3(5, 5, 5)))]
+        for k in range(6):
+            r = float(10 ** rng.uniform(1, 4.5))
+            pos = [0.0, 0.0, 0.0]
+            pos[k // 2] = (r + half * float(rng.uniform(0.8, 1.2))) * (1 if k % 2 == 0 else -1)
+            objs.append(sphere(pos, r, rng.uniform(0.2, 0.9, 3)))
+        cam = rtm.Camera(rtm.vec3(*map(float, rng.uniform(-0.7, 0.7, 3) * half)), rtm.vec3(*map(float, rng.uniform(-0.2, 0.2, 3) * half)),
+                         rtm.vec3(0, 1, 0), float(rng.uniform(0.8, 2.0)))
         data = rtm.SettingData(width=8, height=8, samples=1, superSamples=1, camera=cam, object=objs)
     elif kind == 0:
         objs = list(box.object)[: max(1, min(n, 7))]

@@ -1122,11 +1122,14 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
                 // scenes under 8 spheres (every shipped scene): the instantiation for exactly n spheres
                 const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
 #if RTM_OPT_AXIS
-                if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (rtm_path.h: sphere_disc)
-                    render_tiles_kernel<M, LDS_TAB, axis_unroll(7, kAxisSigCornell7), RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL>
-                        <<<grid, 64, lds, stream>>>(P);
-                    return;
-                }
+#define RTM_AXIS_CASE(k, sig)                                                                                                  \
+    if (P.scene.n == k && P.scene.axis_pat == sig) { /* rtm_path.h: sphere_disc */                                             \
+        render_tiles_kernel<M, LDS_TAB, axis_unroll(k, sig), RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL> \
+            <<<grid, 64, lds, stream>>>(P);                                                                                    \
+        return;                                                                                                                \
+    }
+                RTM_AXIS_SIGNATURES(RTM_AXIS_CASE)
+#undef RTM_AXIS_CASE
 #endif
                 switch (P.scene.n) {
 #define RTM_EXACT_N(k)                                                                                     \
@@ -1155,11 +1158,14 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
             const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL);  // (10 072 bytes for a 7-sphere scene: no room)
 #if RTM_OPT_AXIS
             if constexpr (UNROLL == -8) {
-                if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (rtm_path.h: sphere_disc)
-                    render_tiles_kernel<M, LDS_TAB, axis_unroll(7, kAxisSigCornell7), RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>
-                        <<<grid, 64, lds, stream>>>(P);
-                    return;
-                }
+#define RTM_AXIS_CASE(k, sig)                                                                                              \
+    if (P.scene.n == k && P.scene.axis_pat == sig) { /* rtm_path.h: sphere_disc */                                         \
+        render_tiles_kernel<M, LDS_TAB, axis_unroll(k, sig), RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>           \
+            <<<grid, 64, lds, stream>>>(P);                                                                                \
+        return;                                                                                                            \
+    }
+                RTM_AXIS_SIGNATURES(RTM_AXIS_CASE)
+#undef RTM_AXIS_CASE
             }
 #endif
             render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>

@@ -43,10 +43,13 @@ static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, 
 template <bool SPLIT>
 static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
-    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (rtm_path.h: sphere_disc)
-        launch_one<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
-        return;
+#define RTM_AXIS_CASE(k, sig)                                                                   \
+    if (P.scene.n == k && P.scene.axis_pat == sig) { /* rtm_path.h: sphere_disc */              \
+        launch_one<axis_unroll(k, sig), SPLIT>(P, grid, lds_pad, stream);                       \
+        return;                                                                                 \
     }
+    RTM_AXIS_SIGNATURES(RTM_AXIS_CASE)
+#undef RTM_AXIS_CASE
 #endif
     switch (P.scene.n) {  // the shipped scenes' sizes run the instantiation for exactly their sphere count
         case 3: launch_one<-103, SPLIT>(P, grid, lds_pad, stream); return;

@@ -844,12 +844,19 @@ struct AxisShared {
     }
 };
 // Axis signatures that have an instantiation of the exact-n kernels (nearest_hit: UNROLL <= -1000; the launchers compare
-// SceneView::axis_pat and the sphere count): ExampleScene/cornellBoxSetting.json — the light on the y axis and the six wall
-// spheres on +x, -x, +y, -y, +z, -z (BASELINE configs[1..3]).  A run-time pattern per sphere (a scalar branch in front of
+// SceneView::axis_pat and the sphere count), RTM_AXIS_SIGNATURES below: the shipped scenes whose spheres sit on the axes.
+// ExampleScene/cornellBoxSetting.json — the light on the y axis and the six wall spheres on +x, -x, +y, -y, +z, -z
+// (BASELINE configs[1..3]).  A run-time pattern per sphere (a scalar branch in front of
 // every discriminant) was measured first and lost: 130.8 -> 139.4 ms for the tolerance row, 160.8 -> 161.6 ms for the exact
 // kernel (profiles/r4/axis_ab.txt) — the patterns' SGPRs spill to VGPR lanes and the chunk stops being one basic block.
 constexpr unsigned kAxisSigCornell7 = 2u | (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (3u << 10) | (3u << 12);
+// ExampleScene/simpleSetting1.json (BASELINE configs[0]): a sphere at the origin (no pattern), two on the x axis, two on the y axis
+constexpr unsigned kAxisSigSimple5 = (1u << 2) | (1u << 4) | (2u << 6) | (2u << 8);
+// settingData.json: the light on the y axis, a sphere at the origin, one on the x axis
+constexpr unsigned kAxisSigSetting3 = 2u | (1u << 4);
 constexpr int axis_unroll(const int n, const unsigned sig) { return -(1000 + n + 8 * (int)sig); }
+// (n, signature) pairs with an instantiation: X(n, sig) for each
+#define RTM_AXIS_SIGNATURES(X) X(7, kAxisSigCornell7) X(5, kAxisSigSimple5) X(3, kAxisSigSetting3)
 // b and D4 of sphere g (src/SettingData.cpp:198-200); pat: 0 general, 1 / 2 / 3 the centre is on the x / y / z axis
 __device__ __forceinline__ void sphere_disc(const double4 g, const unsigned pat, const D3 org, const D3 dir,
                                             const AxisShared& A, double& b, double& D4) {
