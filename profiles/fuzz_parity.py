@@ -96,7 +96,7 @@ for case in range(cases):
     m = oracle.MODE_LITERAL if mode == "literal" else oracle.MODE_REPAIRED
     if data.has_planes():
         variant = int(rng.choice([0, 0, 1, 2, 9])) if n < 256 else int(rng.choice([0, 0, 1, 17]))
-    tol = (not data.has_planes()) and 1 <= n <= 24 and 0 <= mb <= 8 and data.samples * data.superSamples ** 2 < 65536 and case % 3 == 2
+    tol = (not data.has_planes()) and 1 <= n <= 24 and data.samples * data.superSamples ** 2 < 65536 and case % 3 == 2  # (any depth since the round's last step)
     if tol:
         variant = 18
     surface = case % 11 == 5 and n >= 1

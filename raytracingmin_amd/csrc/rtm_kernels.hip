@@ -1910,10 +1910,8 @@ static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, 
     const bool tol = variant == kVariantTol;
     plan.tol = tol;
     if (tol) {
-        if (!(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && view.plane == nullptr && P.max_bounces >= 0 && P.max_bounces <= 8 &&
-              P.total_samples < 65536u)) {
-            set_last_error("variant 18 (fp64 tolerance row) serves all-sphere scenes of 1..24 spheres with 0 <= max_bounces <= 8 and "
-                           "fewer than 65 536 samples per pixel");
+        if (!(n >= 1 && n <= (size_t)kAutoLdsTableSpheres && view.plane == nullptr && P.total_samples < 65536u)) {
+            set_last_error("variant 18 (fp64 tolerance row) serves all-sphere scenes of 1..24 spheres with fewer than 65 536 samples per pixel");
             return RTM_ERR_UNSUPPORTED;
         }
         variant = kVariantFastLds;
@@ -1984,10 +1982,10 @@ static int plan_render(const rtm_settings* st, const SceneView& view, size_t n, 
         plan.steal_depth = depth;
         plan.bytes[kScratchSteal] = (size_t)n_whole * steal_tile_bytes(rows);
         plan.optional[kScratchSteal] = !tol;
-    } else if (tol) {
-        // the tolerance row has the STEAL instantiation only: frames the stealing declines (fewer than 16 samples per pixel)
-        // run it with no row to steal into — every lane traces its own samples, the tile's block carries the accumulators
-        // to steal_finalize_kernel
+    } else if (tol && P.max_bounces >= 0 && P.max_bounces <= 8) {
+        // the depth-capped tolerance row has the STEAL instantiation only: frames the stealing declines (fewer than 16 samples
+        // per pixel) run it with no row to steal into — every lane traces its own samples, the tile's block carries the
+        // accumulators to steal_finalize_kernel.  (Any other depth: the any-depth kernel, which has no stealing.)
         plan.bytes[kScratchSteal] = (size_t)(n_whole ? n_whole : 1) * steal_tile_bytes(0);
     }
     // the pre-pass table of the deferred-fold kernels: primary directions (optional), the tolerance row's masks (needed)

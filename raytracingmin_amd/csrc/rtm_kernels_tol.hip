@@ -12,9 +12,10 @@
 //   * the fold L = colorKD * L + emission (src/Renderer.cpp:109) kept unfused (rtm_device.h: fold_step), so that a
 //     sample's value stays a function of its path's hit ids alone: the image differs from the exact kernel's only where
 //     a last-bit difference in a distance or a direction changes WHICH sphere a ray hits.
-// What is instantiated: the default kernel of scenes up to 24 spheres with a depth cap of at most 8 (LDS tables, chunked
-// search, packed records, deferred fold, in-wave sample stealing, the sample split of a launch's last tiles) — the class
-// of every BASELINE Cornell configuration.  Never the default; bench.py reports it as a labelled row with its own
+// What is instantiated: the default kernels of scenes up to 24 spheres — with a depth cap of at most 8 the LDS tables, chunked
+// search, packed records, deferred fold, in-wave sample stealing and the sample split of a launch's last tiles; for any other
+// depth (the reference's own unlimited recursion) the same with records packed by position and the pooled stack, no
+// stealing — the class of every BASELINE Cornell configuration.  Never the default; bench.py reports it as a labelled row with its own
 // roofline fraction and the count of pixels that differ from the exact frame (tests/test_tolerance_gpu.py).
 #define RTM_NS rtm_tol
 #define RTM_TOL 1
@@ -40,6 +41,29 @@ static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, 
     render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, false, true>
         <<<grid, 64, lds, stream>>>(P);
 }
+// Any depth (max_bounces < 0 — the reference's own semantics — or > 8): the deferred fold with records packed by position
+// and the pooled stack from level 16 (PACKL, rtm_render_kernel.h), no in-wave stealing; a whole tile stores its own pixels.
+template <int UNROLL, bool SPLIT>
+static void launch_one_any(const RenderParams& P_in, unsigned grid, size_t lds_pad, hipStream_t stream) {
+    RenderParams P = P_in;
+    size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + kFoldQueueBytesL + lds_pad;
+    P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
+    if (P.unit_tab) lds += (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);
+    // <M, LDS_TAB, UNROLL, RecT, LDS_D, WPE, PARK, STAMP, PACK8, SPLIT, DEFER, PACKL>
+    render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 0, 4, true, false, false, SPLIT, true, true><<<grid, 64, lds, stream>>>(P);
+}
+template <bool SPLIT>
+static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
+#if RTM_OPT_AXIS
+    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
+        launch_one_any<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
+        return;
+    }
+#endif
+    if (P.scene.n < 8) launch_one_any<-8, SPLIT>(P, grid, lds_pad, stream);
+    else launch_one_any<8, SPLIT>(P, grid, lds_pad, stream);
+}
+
 template <bool SPLIT>
 static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
@@ -111,10 +135,10 @@ int launch_tol(const void* params, size_t params_bytes, unsigned grid, size_t ld
     // ten instructions per bounce less); the flag is accepted and has no effect here.
     P.scene.trig_fix = nullptr;
     hipStream_t stream = (hipStream_t)stream_v;
-    if (P.steal_ws == nullptr || P.scene.n < 1 || P.scene.n > 24 || P.scene.plane != nullptr || P.max_bounces < 0 ||
-        P.max_bounces > 8 || P.total_samples >= 65536u) {
-        set_last_error("variant 18 (fp64 tolerance row) serves all-sphere scenes of 1..24 spheres with 0 <= max_bounces <= 8 and "
-                       "fewer than 65 536 samples per pixel");
+    const bool any_depth = P.max_bounces < 0 || P.max_bounces > 8;
+    if ((!any_depth && P.steal_ws == nullptr) || P.scene.n < 1 || P.scene.n > 24 || P.scene.plane != nullptr ||
+        P.total_samples >= 65536u) {
+        set_last_error("variant 18 (fp64 tolerance row) serves all-sphere scenes of 1..24 spheres with fewer than 65 536 samples per pixel");
         return RTM_ERR_UNSUPPORTED;
     }
     if (P.prim_masks == nullptr) {
@@ -133,14 +157,23 @@ int launch_tol(const void* params, size_t params_bytes, unsigned grid, size_t ld
     else
         rtm_tol::prim_prepass_kernel<<<n_tiles_all, 64, 0, stream>>>(P, const_cast<unsigned long long*>(P.prim_masks),
                                                                  const_cast<double*>(P.prim_dirs));
-    if (P.split > 1) {
-        rtm_tol::launch_n<true>(P, P.split_first + P.n_tiles * P.split, lds_pad, stream);
-        rtm_tol::split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
+    if (any_depth) {  // (no stealing: every whole tile stores its pixels itself)
+        if (P.split > 1) {
+            rtm_tol::launch_n_any<true>(P, P.split_first + P.n_tiles * P.split, lds_pad, stream);
+            rtm_tol::split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
+        } else {
+            rtm_tol::launch_n_any<false>(P, grid, lds_pad, stream);
+        }
     } else {
-        rtm_tol::launch_n<false>(P, grid, lds_pad, stream);
+        if (P.split > 1) {
+            rtm_tol::launch_n<true>(P, P.split_first + P.n_tiles * P.split, lds_pad, stream);
+            rtm_tol::split_finalize_kernel<<<P.n_tiles, 256, (size_t)P.split_len * 64 * 3 * sizeof(double), stream>>>(P);
+        } else {
+            rtm_tol::launch_n<false>(P, grid, lds_pad, stream);
+        }
+        const unsigned n_whole = P.split > 1 ? P.split_first : grid;
+        if (n_whole) rtm_tol::steal_finalize_kernel<<<n_whole, 64, (size_t)P.steal_depth * 64 * sizeof(unsigned short), stream>>>(P);
     }
-    const unsigned n_whole = P.split > 1 ? P.split_first : grid;
-    if (n_whole) rtm_tol::steal_finalize_kernel<<<n_whole, 64, (size_t)P.steal_depth * 64 * sizeof(unsigned short), stream>>>(P);
     if (hipGetLastError() != hipSuccess) {
         set_last_error("tolerance row: launch failed");
         return RTM_ERR_HIP;

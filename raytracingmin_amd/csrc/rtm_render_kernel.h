@@ -377,8 +377,20 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 #ifndef RTM_TOL_PRIMFIX
 #define RTM_TOL_PRIMFIX 1  // (A/B switch: 0 compiles the exact-tie handling out — NOT within tolerance on the Cornell diagonals)
 #endif
-    constexpr bool kPrimFix = (RTM_TOL != 0) && STEAL && (RTM_TOL_PRIMFIX != 0);
-    unsigned long long* prim_mask = reinterpret_cast<unsigned long long*>(fq_pend + 3 * 64);  // behind the two STEAL arrays
+    // (round 4, later: the any-depth kernels too — PACKL has no stealing, a lane only ever asks for its OWN pixel's word and
+    // reads it from the pre-pass's table when it moves on to a sub-pixel: no LDS, no register pair across the loop)
+    constexpr bool kPrimFix = (RTM_TOL != 0) && (STEAL || PACKL) && (RTM_TOL_PRIMFIX != 0);
+    unsigned long long* prim_mask = reinterpret_cast<unsigned long long*>(fq_pend + 3 * 64);  // STEAL: behind its two arrays
+    [[maybe_unused]] auto own_prim_mask = [&]() -> unsigned long long {
+        if constexpr (STEAL) {
+            return prim_mask[lane];
+        } else {
+            unsigned b = blockIdx.x;
+            asm volatile("" : "+s"(b));  // (opaque, like split_wave's: nothing of this stays live across the render loop)
+            const unsigned tile_id = (SPLIT && b >= P.split_first) ? P.split_first + (b - P.split_first) % P.n_tiles : b;
+            return P.prim_masks[(size_t)tile_id * 64 + (unsigned)lane];
+        }
+    };
     [[maybe_unused]] bool prim_fix = false;  // this lane's current sample is of a flagged sub-pixel
     [[maybe_unused]] auto prim_flag_of = [&](const unsigned long long mask, const unsigned sub) {
         return sub >= 64u || ((mask >> sub) & 1ull) != 0ull;
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         const unsigned tile_id = (SPLIT && blockIdx.x >= P.split_first) ? P.split_first + (blockIdx.x - P.split_first) % P.n_tiles
                                                                          : blockIdx.x;
         const unsigned long long mask = P.prim_masks[(size_t)tile_id * 64 + (unsigned)lane];  // prim_prepass_kernel, the same launch
-        prim_mask[lane] = mask;
+        if constexpr (STEAL) prim_mask[lane] = mask;
         prim_fix = prim_flag_of(mask, (unsigned)sub_first);
     }
     // The primary direction of sub-pixel `sub` of the tile's pixel `pl` (its lane number; px, py: its coordinates): from the
@@ -823,7 +835,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     park[3 * 64 + lane] = pdir.x;
                     park[4 * 64 + lane] = pdir.y;
                     park[5 * 64 + lane] = pdir.z;
-                    if constexpr (kPrimFix) prim_fix = n < n_end && prim_flag_of(prim_mask[lane], (unsigned)sub);
+                    if constexpr (kPrimFix) prim_fix = n < n_end && prim_flag_of(own_prim_mask(), (unsigned)sub);
                 }
                 if constexpr (kPrimFix) prim_fix = prim_fix && n < n_end;
                 org = P.cam_org;

@@ -176,9 +176,6 @@ def test_tolerance_row_without_stealing_and_what_it_refuses(rtm, oracle):
         del os.environ["RTM_DEBUG_TOL_NOSTEAL"]
     assert np.array_equal(with_steal["f64"].cpu().numpy().view(np.uint64), without["f64"].cpu().numpy().view(np.uint64))
     assert s1["casts"] == s2["casts"]
-    for kwargs in (dict(max_bounces=-1), dict(max_bounces=9)):
-        with pytest.raises(rtm.RtmError, match="variant 18"):
-            rtm.Renderer(data, mode="repaired", seed=3, variant=TOL_VARIANT, **kwargs).render_rows_device(want=("f64",))
     big = rtm.make_stress_scene(n=40, seed=1)
     big.width, big.height, big.samples, big.superSamples = 16, 16, 1, 1
     with pytest.raises(rtm.RtmError, match="variant 18"):
@@ -187,3 +184,36 @@ def test_tolerance_row_without_stealing_and_what_it_refuses(rtm, oracle):
     room.width, room.height, room.samples, room.superSamples = 16, 16, 1, 1
     with pytest.raises(rtm.RtmError):
         rtm.Renderer(room, mode="repaired", max_bounces=8, seed=3, variant=TOL_VARIANT).render_rows_device(want=("f64",))
+
+
+def test_tolerance_row_at_any_depth(rtm, oracle):
+    """max_bounces < 0 (the reference's own unlimited recursion) and caps above 8: the row's any-depth kernel (records packed
+    by position, pooled stack, no stealing; exact primary rays and risky primary hits settled in the reference's arithmetic
+    like the capped kernel's).  BASELINE configs[1] as the reference itself runs it — 512x512 @ 256 spp, unlimited — whole,
+    a band part of the headline frame unlimited, small frames of every shipped scene against the ORACLE: <= 1e-4 per pixel
+    (observed: none differ), counters equal."""
+    scene = oracle.scene_path("cornellBoxSetting.json")
+    data = rtm.LoadData(scene).data
+    for label, (w, h, s, ss), band, mb in (("configs[1] 512x512 @ 256 spp, unlimited depth", (512, 512, 16, 4), None, -1),
+                                           ("configs[1] 512x512 @ 256 spp, cap 12", (512, 512, 16, 4), None, 12),
+                                           ("headline frame, unlimited depth, band part 5 of 8", (1920, 1080, 64, 4), (8, 5), -1)):
+        data.width, data.height, data.samples, data.superSamples = w, h, s, ss
+        exact, es, tol, ts = _frames(rtm, data, mb, 0x5EED, band=band)
+        worst, differing, same = _report(label, exact, es, tol, ts)
+        # (an unlimited path is long enough for ONE of a frame's 1e9 casts to meet a last-bit tie now and then: first seen on the
+        # headline band part — 1 pixel of 261 120 differs, by 2.6e-15, and the diverged path draws a few numbers more or fewer;
+        # the bar is the pixels', the counters are reported)
+        assert worst <= NORTH_STAR_TOL
+        assert abs(ts["casts"] - es["casts"]) <= 1e-6 * es["casts"]
+    for name, (w, h, s, ss) in (("cornellBoxSetting.json", (96, 64, 4, 2)), ("simpleSetting1.json", (80, 48, 16, 1)),
+                                ("simpleSetting2.json", (64, 40, 8, 2)), ("settingData.json", (48, 48, 4, 3))):
+        st, arr, n = oracle.load_scene(oracle.scene_path(name), width=w, height=h, samples=s, super_samples=ss)
+        d = rtm.LoadData(oracle.scene_path(name)).data
+        d.width, d.height, d.samples, d.superSamples = w, h, s, ss
+        for mb in (-1, 9, 40):
+            ref, cnt = oracle.render(st, arr, n, oracle.make_options(mode=1, max_bounces=mb, seed=11, height=h))
+            out, stats = rtm.Renderer(d, mode="repaired", max_bounces=mb, seed=11, variant=TOL_VARIANT).render_rows_device(want=("f64",))
+            assert stats["variant"] == TOL_VARIANT
+            delta = float(np.nanmax(np.abs(out["f64"].cpu().numpy() - ref)))
+            assert delta <= NORTH_STAR_TOL, (name, mb, delta)
+            assert abs(stats["casts"] - cnt["casts"]) <= 1e-4 * cnt["casts"] + 8, (name, mb)
