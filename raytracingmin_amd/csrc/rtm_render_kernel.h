@@ -301,7 +301,21 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     // SPLIT, small waves only: tag of every ring entry, in the FIFO array they have no other use for
     unsigned short* fq_tag = reinterpret_cast<unsigned short*>(fq_fifo);
     static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
-    if constexpr (DEFER) fq_pend[lane] = 0u;
+    // Who adds a folded term to its pixel (fold_pass).  Round 1's form: the OWNER finds its entries through a per-lane FIFO of
+    // ring positions and reads the terms back from LDS — as many rounds as the busiest pixel has entries in the pass, each with
+    // the FIFO's decoding (23 vector instructions and 10 LDS operations a round, ~4.5 rounds a pass).  kScatter (round 4, the
+    // packed-record kernels): the entry carries (owner lane, the owner's running count of path ends) and the FOLDING lane adds
+    // its term to the owner's accumulator itself, in the round that is the entry's turn — rank = count - the owner's count of
+    // entries already added (fq_done) — straight from its registers: a compare, three LDS read-add-writes and the count per
+    // round, no FIFO, no term staging, and no forced passes (a FIFO held 8 positions).  The order of a pixel's additions is the
+    // order of its path ends either way.
+#ifndef RTM_OPT_SCATTER
+#define RTM_OPT_SCATTER 1
+#endif
+    constexpr bool kScatter = (RTM_OPT_SCATTER != 0) && DEFER && PACK8 && !REUSE;
+    unsigned* fq_done = reinterpret_cast<unsigned*>(fq_fifo);  // kScatter: per lane, entries of its pixel added so far (the FIFO's place)
+    if constexpr (DEFER) fq_pend[lane] = 0u;  // entries waiting (FIFO form) / path ends so far (kScatter)
+    if constexpr (kScatter) fq_done[lane] = 0u;
     if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
     fill_shade_consts(trig, lane, unit_tab);
     if (lane < 9) {
@@ -517,6 +531,8 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         constexpr bool SMALL = SPLIT && MODE == 1;
         constexpr bool TAIL = STEAL && MODE == 2;
         if constexpr (TAIL) tail_tag = 0u;
+        [[maybe_unused]] D3 scatter_add = d3(0, 0, 0);
+        [[maybe_unused]] unsigned scatter_w = 0x80000000u;  // (a lane without an entry: nobody's)
         const unsigned m = fq_count < 64u ? fq_count : 64u;
         if ((unsigned)lane < m) {
             const unsigned at = (fq_head + (unsigned)lane) & (kFoldRing - 1);
@@ -554,6 +570,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     // of that lane is waiting (two folding lanes may serve the same owner in one pass: an LDS atomic)
                     if ((e.z >> 8) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
                 }
+            } else if constexpr (kScatter) {
+                scatter_add = add;
+                scatter_w = e.w;  // own sample: owner lane | count << 8; stolen (TAIL): 0x80000000 | pixel lane << 16 | sample
+                if constexpr (TAIL) {
+                    tail_add = add;
+                    tail_tag = (e.w >> 31) != 0u ? e.w : 0u;
+                }
             } else {
                 if constexpr (TAIL) {
                     tail_add = add;
@@ -587,6 +610,20 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         }
         if constexpr (SMALL) {
             terms_out += m;
+        } else if constexpr (kScatter) {
+            // every folding lane adds its term to its entry's pixel when it is the entry's turn (:241-242 on the LDS accumulator)
+            const bool own_entry = (scatter_w >> 31) == 0u;
+            const unsigned owner = scatter_w & 63u, count = (scatter_w >> 8) & 0xFFu;
+            const unsigned rank = own_entry ? ((count - fq_done[owner]) & 0xFFu) : 0xFFFFFFFFu;  // 0: the pixel's next term
+            for (unsigned round = 0u;; ++round) {
+                if (__builtin_amdgcn_ballot_w64(own_entry && rank >= round) == 0) break;
+                if (own_entry && rank == round) {
+                    park[0 * 64 + owner] += scatter_add.x;
+                    park[1 * 64 + owner] += scatter_add.y;
+                    park[2 * 64 + owner] += scatter_add.z;
+                    fq_done[owner] = count + 1u;  // (rounds go in order: the last write is the pixel's last entry of the pass)
+                }
+            }
         } else {
             // every owner adds its terms of this pass, oldest first (:241-242 on the LDS accumulator)
             for (;;) {
@@ -787,12 +824,18 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
                                            (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
                         fq_in1[pos] = rec_w1[lane];
+                    } else if constexpr (kScatter && !SMALL) {
+                        // (fold_pass: the folding lane adds the term to this lane's pixel when the count says it is its turn)
+                        const unsigned ends_so_far = fq_pend[lane];
+                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, (unsigned)lane | ((ends_so_far & 0xFFu) << 8)};
+                        fq_pend[lane] = ends_so_far + 1u;
                     } else {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
                     }
                     if constexpr (SPLIT) {
                         if constexpr (SMALL) fq_tag[pos] = (unsigned short)((unsigned)lane | ((n - n_first) << 6));
                     }
+                    if constexpr (!(kScatter && !SMALL)) {
                     // whole waves: count of the lane's waiting entries, and (PACKL) bit 8: a deep entry of the lane may be waiting.
                     // A small wave never picks its terms up again, so it keeps no count — only (PACKL) the NUMBER of the
                     // lane's deep entries still waiting, in bits 8 up, taken down by whoever folds one (fold_pass)
@@ -818,6 +861,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                             stack.slot ^= 1;
                         }
                     }
+                    }  // (the FIFO form, or a small wave)
                 }
                 if constexpr (PACKL) {
                     if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
@@ -920,12 +964,19 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
                 const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
                 const bool own = (cur >> 16) == (unsigned)lane;
+                if constexpr (kScatter) {
+                    const unsigned ends_so_far = fq_pend[lane];  // (of this lane's OWN pixel)
+                    fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id,
+                                       own ? ((unsigned)lane | ((ends_so_far & 0xFFu) << 8)) : (0x80000000u | cur)};
+                    if (own) fq_pend[lane] = ends_so_far + 1u;
+                } else {
                 fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, own ? 0u : (0x80000000u | cur)};
                 if (own) {  // the owner picks its term up again, in the order its paths ended
                     const unsigned pend = (fq_pend[lane] & 0xFFu) + 1u;
                     fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
                     fq_pend[lane] = pend;
                     fifo_full = pend >= 8u;
+                }
                 }
             }
             const unsigned added = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ended));
