@@ -55,7 +55,7 @@ static void launch_one_any(const RenderParams& P_in, unsigned grid, size_t lds_p
 template <bool SPLIT>
 static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
-    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
+    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
         launch_one_any<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
         return;
     }
@@ -68,7 +68,7 @@ template <bool SPLIT>
 static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
 #define RTM_AXIS_CASE(k, sig)                                                                   \
-    if (P.scene.n == k && P.scene.axis_pat == sig) { /* rtm_path.h: sphere_disc */              \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED) { /* rtm_path.h: sphere_disc */              \
         launch_one<axis_unroll(k, sig), SPLIT>(P, grid, lds_pad, stream);                       \
         return;                                                                                 \
     }

@@ -628,6 +628,7 @@ struct SceneGlobal {
     SceneView v;
     static constexpr bool kHasNormTable = false;
     static constexpr bool kPlanes = false;  // (planes, if any, are found at run time: v.plane, the per-object loop)
+    static constexpr bool kNeverPlanes = false;
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -656,6 +657,10 @@ struct SceneLds {
                           // on the sphere, (double)sqrtf((float)(r*r)), its refined reciprocal, the float r*r
     static constexpr bool kHasNormTable = true;
     static constexpr bool kPlanes = false;
+#ifndef RTM_OPT_CTMODE
+#define RTM_OPT_CTMODE 1
+#endif
+    static constexpr bool kNeverPlanes = RTM_OPT_CTMODE != 0;  // the launchers hand scenes that hold planes to SceneLdsObjects (v.plane is null here)
     __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 3]; }
     __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 3 + 1]; }
     __device__ __forceinline__ float norm_r2f(int id) const { return reinterpret_cast<const float*>(lnrm + id * 3 + 2)[0]; }
@@ -688,6 +693,7 @@ struct SceneLdsObjects {
     const double* lnrm;   // LDS, 3 doubles per object: a plane's m_normal (unused for spheres)
     static constexpr bool kHasNormTable = false;
     static constexpr bool kPlanes = true;
+    static constexpr bool kNeverPlanes = false;
     __device__ __forceinline__ int n() const { return v.n; }
     __device__ __forceinline__ double4 geom_uniform(int i) const { return load_geom_uniform(v.geom, i); }
     __device__ __forceinline__ D3 center(int id) const {
@@ -1601,7 +1607,7 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
             if constexpr (is_spec<MI>::value) m.bad = bad_before || (m.bad && !is_plane);
             const D3 pn = sc.plane_normal(id);
             normal = is_plane ? pn : nsphere;  // PlaneObject: out_normal = m_normal
-        } else if (sc.v.plane != nullptr) {  // wave-uniform: the scene holds planes (per-object kernel, MathRefI)
+        } else if (!Scene::kNeverPlanes && sc.v.plane != nullptr) {  // wave-uniform: the scene holds planes (per-object kernel, MathRefI)
             const bool is_plane = sc.v.geom[id].w < 0.0;
             const double* pl = sc.v.plane + (size_t)id * 16;
             const D3 nsphere = normalize_i(m, hit_point - sc.center(id));

@@ -354,6 +354,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                             typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type>::type;
     Scene sc;
     sc.v = P.scene;
+    // The axis-signature instantiations (UNROLL <= -1000) are launched for RTM_MODE_REPAIRED only: the mode is a compile-time
+    // constant there (the shading block's "literal mode: the normal stays 0" arm and its wave-uniform test go away; a literal-mode
+    // render of such a scene takes the plain exact-n kernel)
+#ifndef RTM_OPT_CTMODE
+#define RTM_OPT_CTMODE 1  // (A/B switch, with SceneLds::kNeverPlanes)
+#endif
+    const int mode = (RTM_OPT_CTMODE && UNROLL <= -1000) ? (int)RTM_MODE_REPAIRED : P.mode;
     if constexpr (LDS_TAB) {
         sc.lgeom = lgeom;
         sc.lmat = lmat;
@@ -738,11 +745,11 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             {
                 MathSpec m;
                 m.set_lds(shade_lds);
-                path_bounce_core(m, sc, sid, dis, P.mode, org, dir, rng, o);
+                path_bounce_core(m, sc, sid, dis, mode, org, dir, rng, o);
                 if (__builtin_amdgcn_ballot_w64(m.bad) != 0) {
                     MathRefI r;
                     r.set_lds(shade_lds);
-                    path_bounce_core(r, sc, sid, dis, P.mode, org, dir, rng, o);
+                    path_bounce_core(r, sc, sid, dis, mode, org, dir, rng, o);
                 }
             }
             w_draws += 2u * n_live;
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 double dis;
                 hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
                 const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
-                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
+                cont = path_shade_spec_fix(sc, hit_id, dis, mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
                                            flagged, [&](int& id_fix, double& dis_fix) {
                                                double dis_ref;
                                                const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                            });
             } else
 #endif
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
+            cont = path_step<M, UNROLL>(sc, mode, P.max_bounces, org, dir, depth, rng, term, unused, push,
                                         shade_lds, &hit_id);
             if (PACKL && cont && stack.overflow) cont = false;  // records exhausted: the call fails loudly
             // counters (src/Renderer.cpp has none; rtm_stats): one cast per live lane, one draw for the RR test of a
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 double dis;
                 hit_id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
                 const bool flagged = prim_fix && depth == 0;  // rare: a primary ray whose hit last-bit differences could change
-                cont = path_shade_spec_fix(sc, hit_id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
+                cont = path_shade_spec_fix(sc, hit_id, dis, mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds,
                                            flagged, [&](int& id_fix, double& dis_fix) {
                                                double dis_ref;
                                                const int id_ref = nearest_hit_exactfp(sc, org, dir, dis_ref);
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                            });
             } else
 #endif
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds, &hit_id);
+            cont = path_step<M, UNROLL>(sc, mode, P.max_bounces, org, dir, depth, rng, term, unused, push, shade_lds, &hit_id);
             const unsigned long long m_cont = __builtin_amdgcn_ballot_w64(cont) & m_busy;
             unsigned long long m_drew = __builtin_amdgcn_ballot_w64(hit_id >= 0) & m_busy;
             if (P.max_bounces >= 0) m_drew &= ~__builtin_amdgcn_ballot_w64(depth_before >= P.max_bounces);
@@ -1085,10 +1092,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             double dis;
             const int id = nearest_hit<M, UNROLL>(sc, org, dir, dis);
             ts1 = stamp_now();
-            cont = path_shade_spec(sc, id, dis, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
+            cont = path_shade_spec(sc, id, dis, mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
             ts2 = stamp_now();
         } else {
-            cont = path_step<M, UNROLL>(sc, P.mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
+            cont = path_step<M, UNROLL>(sc, mode, P.max_bounces, org, dir, depth, rng, term, pc, push, shade_lds);
         }
         if (cont && stack.overflow) {  // records exhausted: stop the path; the call fails loudly
             cont = false;
