@@ -24,6 +24,12 @@
 #ifndef RTM_OPT_AXIS
 #define RTM_OPT_AXIS 1  // axis-signature instantiations of the exact-n kernels (sphere_disc; A/B switch)
 #endif
+#ifndef RTM_OPT_CTMODE
+#define RTM_OPT_CTMODE 1  // what an instantiation knows at compile time: its mode (axis signatures), "no planes" (SceneLds) ...
+#endif
+#ifndef RTM_OPT_CTN
+#define RTM_OPT_CTN 0     // ... and (NOT kept: profiles/r4/ctn_ab.txt — nothing for the tolerance row, +3 % for the exact kernel,
+#endif                    // whose register allocation it upsets) its sphere count in the exact-n instantiations; A/B switches
 
 #include "../../include/rtm.h"
 #include "rtm_device.h"
@@ -657,9 +663,6 @@ struct SceneLds {
                           // on the sphere, (double)sqrtf((float)(r*r)), its refined reciprocal, the float r*r
     static constexpr bool kHasNormTable = true;
     static constexpr bool kPlanes = false;
-#ifndef RTM_OPT_CTMODE
-#define RTM_OPT_CTMODE 1
-#endif
     static constexpr bool kNeverPlanes = RTM_OPT_CTMODE != 0;  // the launchers hand scenes that hold planes to SceneLdsObjects (v.plane is null here)
     __device__ __forceinline__ double norm_m(int id) const { return lnrm[id * 3]; }
     __device__ __forceinline__ double norm_rinv(int id) const { return lnrm[id * 3 + 1]; }

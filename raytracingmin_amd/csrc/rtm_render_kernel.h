@@ -281,10 +281,16 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     static_assert(!PACKL || (DEFER && !PACK8 && LDS_D == 0 && sizeof(RecT) == 1), "PACKL: deferred fold, byte records, pooled stack only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
+    // The exact-n instantiations (UNROLL in -101 .. -107, or an axis signature: UNROLL <= -1000) are launched for scenes of
+    // exactly that many spheres, so the count COULD be a compile-time constant there (the LDS tables' offsets, the identity
+    // row's index and the empty record word as immediates).  Measured and not kept (RTM_OPT_CTN, profiles/r4/ctn_ab.txt): the
+    // tolerance row does not move, the exact kernel loses 3 %.
+    const int scene_n = (RTM_OPT_CTN && UNROLL <= -1000) ? ((-UNROLL - 1000) & 7)
+                        : (RTM_OPT_CTN && UNROLL <= -101 && UNROLL >= -107) ? (-UNROLL - 100) : P.scene.n;
     double* lgeom = reinterpret_cast<double*>(lds_raw);
-    double* lmat = lgeom + (LDS_TAB ? P.scene.n * 4 : 0);
-    double* lnrm = lmat + (LDS_TAB ? (P.scene.n + 1) * 8 : 0);
-    double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(P.scene.n) : 0));
+    double* lmat = lgeom + (LDS_TAB ? scene_n * 4 : 0);
+    double* lnrm = lmat + (LDS_TAB ? (scene_n + 1) * 8 : 0);
+    double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(scene_n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
     // the shading constants: sincos and — where the launcher found the LDS for it — the near-unit Normalize table
     const bool unit_tab = P.unit_tab != 0u;  // wave-uniform
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     unsigned* fq_done = reinterpret_cast<unsigned*>(fq_fifo);  // kScatter: per lane, entries of its pixel added so far (the FIFO's place)
     if constexpr (DEFER) fq_pend[lane] = 0u;  // entries waiting (FIFO form) / path ends so far (kScatter)
     if constexpr (kScatter) fq_done[lane] = 0u;
-    if constexpr (PACKL) rec_w1[lane] = packed8_empty(P.scene.n);
+    if constexpr (PACKL) rec_w1[lane] = packed8_empty(scene_n);
     fill_shade_consts(trig, lane, unit_tab);
     if (lane < 9) {
         const double v9[9] = {P.ax.x, P.ax.y, P.ax.z, P.by.x, P.by.y, P.by.z, P.cz.x, P.cz.y, P.cz.z};
@@ -334,9 +340,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     __syncthreads();
     if constexpr (LDS_TAB) {
         const double* gsrc = reinterpret_cast<const double*>(P.scene.geom);
-        for (int i = lane; i < P.scene.n * 4; i += 64) lgeom[i] = gsrc[i];
-        for (int i = lane; i < (P.scene.n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
-        for (int i = lane; i < P.scene.n; i += 64) {
+        for (int i = lane; i < scene_n * 4; i += 64) lgeom[i] = gsrc[i];
+        for (int i = lane; i < (scene_n + 1) * 8; i += 64) lmat[i] = P.scene.mat[i];
+        for (int i = lane; i < scene_n; i += 64) {
             if (PLANES && gsrc[i * 4 + 3] < 0.0) {  // a plane's row: its normal (SceneLdsObjects::plane_normal)
                 lnrm[i * 3] = P.scene.plane[(size_t)i * 16 + 3];
                 lnrm[i * 3 + 1] = P.scene.plane[(size_t)i * 16 + 4];
@@ -354,12 +360,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                             typename std::conditional<LDS_TAB, SceneLds, SceneGlobal>::type>::type;
     Scene sc;
     sc.v = P.scene;
+    sc.v.n = scene_n;
     // The axis-signature instantiations (UNROLL <= -1000) are launched for RTM_MODE_REPAIRED only: the mode is a compile-time
     // constant there (the shading block's "literal mode: the normal stays 0" arm and its wave-uniform test go away; a literal-mode
     // render of such a scene takes the plain exact-n kernel)
-#ifndef RTM_OPT_CTMODE
-#define RTM_OPT_CTMODE 1  // (A/B switch, with SceneLds::kNeverPlanes)
-#endif
     const int mode = (RTM_OPT_CTMODE && UNROLL <= -1000) ? (int)RTM_MODE_REPAIRED : P.mode;
     if constexpr (LDS_TAB) {
         sc.lgeom = lgeom;
@@ -506,13 +510,13 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
         park[5 * 64 + lane] = pdir.z;
     }
 
-    unsigned long long recq = packed8_empty(P.scene.n);  // PACK8 records, most recent bounce in the low byte
+    unsigned long long recq = packed8_empty(scene_n);  // PACK8 records, most recent bounce in the low byte
     auto push = [&](int d, int id) {
         if constexpr (PACK8) {
             recq = (recq << 8) | (unsigned long long)(unsigned)id;
         } else if constexpr (PACKL) {
             // the byte still holds the identity index: xor turns it into id
-            const unsigned long long flip = (unsigned long long)((unsigned)id ^ (unsigned)P.scene.n) << (8 * (d & 7));
+            const unsigned long long flip = (unsigned long long)((unsigned)id ^ (unsigned)scene_n) << (8 * (d & 7));
             if (d < 8)
                 recq ^= flip;
             else if (d < 16)
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
                         const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                        const unsigned term_id = (unsigned)(id < 0 ? P.scene.n : id);
+                        const unsigned term_id = (unsigned)(id < 0 ? scene_n : id);
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id, 0u};
                         const unsigned pend = fq_pend[lane] + 1u;
                         fq_fifo[lane] = (fq_fifo[lane] << 8) | pos;
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                         org = P.cam_org;
                         dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
                         depth = 0;
-                        recq = packed8_empty(P.scene.n);
+                        recq = packed8_empty(scene_n);
                         rng = rng_open(pkey, n);
                         id = pid;
                         dis = pdis;
@@ -826,7 +830,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
                     const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                    const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
+                    const unsigned term_id = (unsigned)(hit_id < 0 ? scene_n : hit_id);
                     if constexpr (PACKL) {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
                                            (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                     }  // (the FIFO form, or a small wave)
                 }
                 if constexpr (PACKL) {
-                    if (depth > 8) rec_w1[lane] = packed8_empty(P.scene.n);
+                    if (depth > 8) rec_w1[lane] = packed8_empty(scene_n);
                 }
                 // next sample of this pixel (src/Renderer.cpp:236-239); a lane past its range stays at n_end, so that
                 // "n - pending" remains the sample index of its queued path ends (fold_pass, SPLIT)
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 org = P.cam_org;
                 dir = d3(park[3 * 64 + lane], park[4 * 64 + lane], park[5 * 64 + lane]);
                 depth = 0;
-                recq = packed8_empty(P.scene.n);
+                recq = packed8_empty(scene_n);
                 rng = rng_open(pkey, n);
             }
             const unsigned added = (unsigned)__builtin_popcountll(m_live & ~m_cont);
@@ -969,7 +973,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 const unsigned long long ending = __builtin_amdgcn_ballot_w64(true);
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ending >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
                 const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
-                const unsigned term_id = (unsigned)(hit_id < 0 ? P.scene.n : hit_id);
+                const unsigned term_id = (unsigned)(hit_id < 0 ? scene_n : hit_id);
                 const bool own = (cur >> 16) == (unsigned)lane;
                 if constexpr (kScatter) {
                     const unsigned ends_so_far = fq_pend[lane];  // (of this lane's OWN pixel)
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 busy = got;
                 org = P.cam_org;
                 depth = 0;
-                recq = packed8_empty(P.scene.n);
+                recq = packed8_empty(scene_n);
                 if constexpr (kPrimFix) prim_fix = prim_fix && got;
             }
             if (added != 0u) {
@@ -1144,7 +1148,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             else
                 dir = pdir;
             depth = 0;
-            if constexpr (PACK8) recq = packed8_empty(P.scene.n);
+            if constexpr (PACK8) recq = packed8_empty(scene_n);
             rng = rng_open(pkey, n);
         }
         if constexpr (STAMP) {
