@@ -1123,7 +1123,7 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
                 const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
 #if RTM_OPT_AXIS
 #define RTM_AXIS_CASE(k, sig)                                                                                                  \
-    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED) { /* rtm_path.h: sphere_disc */                                             \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && P.unit_tab == 1u) { /* rtm_path.h: sphere_disc */                        \
         render_tiles_kernel<M, LDS_TAB, axis_unroll(k, sig), RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL> \
             <<<grid, 64, lds, stream>>>(P);                                                                                    \
         return;                                                                                                                \
@@ -1159,7 +1159,7 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
 #if RTM_OPT_AXIS
             if constexpr (UNROLL == -8) {
 #define RTM_AXIS_CASE(k, sig)                                                                                              \
-    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED) { /* rtm_path.h: sphere_disc */                                         \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && P.unit_tab == 0u) { /* rtm_path.h: sphere_disc */                    \
         render_tiles_kernel<M, LDS_TAB, axis_unroll(k, sig), RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>           \
             <<<grid, 64, lds, stream>>>(P);                                                                                \
         return;                                                                                                            \

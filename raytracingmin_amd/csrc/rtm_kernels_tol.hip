@@ -55,7 +55,9 @@ static void launch_one_any(const RenderParams& P_in, unsigned grid, size_t lds_p
 template <bool SPLIT>
 static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
-    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
+    const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                                            kFoldQueueBytesL + lds_pad);  // (launch_one_any's rule: no room at 7 spheres)
+    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED && !table_fits) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
         launch_one_any<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
         return;
     }
@@ -67,8 +69,11 @@ static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, h
 template <bool SPLIT>
 static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
+    // (the axis-signature instantiations take the near-unit Normalize table's presence as a compile-time fact: launch_one's rule)
+    const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
+                                            kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) + lds_pad);
 #define RTM_AXIS_CASE(k, sig)                                                                   \
-    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED) { /* rtm_path.h: sphere_disc */              \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && table_fits) { /* rtm_path.h: sphere_disc */ \
         launch_one<axis_unroll(k, sig), SPLIT>(P, grid, lds_pad, stream);                       \
         return;                                                                                 \
     }

@@ -293,7 +293,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(scene_n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
     // the shading constants: sincos and — where the launcher found the LDS for it — the near-unit Normalize table
-    const bool unit_tab = P.unit_tab != 0u;  // wave-uniform
+    // wave-uniform; the axis-signature instantiations are launched only when the table's presence is what their flavour implies
+    // (depth-capped: there; any depth: not there — the launchers check), so it is a compile-time constant for them
+#ifndef RTM_OPT_CTTAB
+#define RTM_OPT_CTTAB 1  // (A/B switch)
+#endif
+    const bool unit_tab = (RTM_OPT_CTTAB && UNROLL <= -1000) ? PACK8 : (P.unit_tab != 0u);
     double* park = trig + (unit_tab ? kShadeConstCount : kTrigConstCount);
     const ShadeLds shade_lds(trig, unit_tab);
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
