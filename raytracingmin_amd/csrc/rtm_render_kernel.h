@@ -323,7 +323,10 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
 #ifndef RTM_OPT_SCATTER
 #define RTM_OPT_SCATTER 1
 #endif
-    constexpr bool kScatter = (RTM_OPT_SCATTER != 0) && DEFER && PACK8 && !REUSE;
+    // (PACKL, the any-depth kernels: owner and count ride in the entry's third word above term id and depth, and the lane's
+    // "may a deep entry of mine still be waiting" is the count it had after its last deep path against fq_done — fq_pend bits
+    // 8..15 and 16)
+    constexpr bool kScatter = (RTM_OPT_SCATTER != 0) && DEFER && (PACK8 || PACKL) && !REUSE;
     unsigned* fq_done = reinterpret_cast<unsigned*>(fq_fifo);  // kScatter: per lane, entries of its pixel added so far (the FIFO's place)
     if constexpr (DEFER) fq_pend[lane] = 0u;  // entries waiting (FIFO form) / path ends so far (kScatter)
     if constexpr (kScatter) fq_done[lane] = 0u;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
             const unsigned long long w0 = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
             D3 L;
             if constexpr (PACKL)
-                L = path_fold_packed16(sc, (int)(e.z & 0xFFu), (int)(e.z >> 8), w0, fq_in1[at],
+                L = path_fold_packed16(sc, (int)(e.z & 0xFFu), (int)((e.z >> 8) & 0x3FFu), w0, fq_in1[at],
                                        P.pool + (size_t)e.w * kPoolLevels);
             else
                 L = path_fold_packed8_all(sc, (int)e.z, w0);
@@ -584,11 +587,12 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                 if constexpr (PACKL) {
                     // this entry's levels from 16 up have just been read from its owner's pooled stack: one deep entry fewer
                     // of that lane is waiting (two folding lanes may serve the same owner in one pass: an LDS atomic)
-                    if ((e.z >> 8) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
+                    if (((e.z >> 8) & 0x3FFu) > 16u) atomicSub(&fq_pend[tag & 63u], 0x100u);
                 }
             } else if constexpr (kScatter) {
                 scatter_add = add;
-                scatter_w = e.w;  // own sample: owner lane | count << 8; stolen (TAIL): 0x80000000 | pixel lane << 16 | sample
+                // own sample: owner lane | count << 8; stolen (TAIL): 0x80000000 | pixel lane << 16 | sample
+                scatter_w = PACKL ? (((e.z >> 18) & 63u) | ((e.z >> 24) << 8)) : e.w;
                 if constexpr (TAIL) {
                     tail_add = add;
                     tail_tag = (e.w >> 31) != 0u ? e.w : 0u;
@@ -836,7 +840,27 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)ending, 0u));
                     const unsigned pos = (fq_tail + rank) & (kFoldRing - 1);
                     const unsigned term_id = (unsigned)(hit_id < 0 ? scene_n : hit_id);
-                    if constexpr (PACKL) {
+                    if constexpr (PACKL && kScatter && !SMALL) {
+                        // fq_pend: bits 0..7 the lane's path ends so far, 8..15 that count after its last DEEP path, 16: there was one
+                        const unsigned word = fq_pend[lane];
+                        const unsigned count = word & 0xFFu, next = (count + 1u) & 0xFFu;
+                        fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32),
+                                           term_id | ((unsigned)depth << 8) | ((unsigned)lane << 18) | (count << 24),
+                                           (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
+                        fq_in1[pos] = rec_w1[lane];
+                        if (depth > 16) {
+                            // Levels from 16 up sit in the lane's pooled stack and are read when the entry is folded; the lane has
+                            // TWO pooled stacks and changes over whenever it queues such a path.  Only if its previous deep entry
+                            // may still be waiting — fq_done has not reached the count the lane had after it (mod 256: a count
+                            // that ran far ahead reads as "waiting", which only costs a pass) — is a pass forced.
+                            const unsigned behind = (((word >> 8) & 0xFFu) - fq_done[lane]) & 0xFFu;
+                            fifo_full = (word & 0x10000u) != 0u && behind != 0u && behind <= 128u;
+                            stack.slot ^= 1;
+                            fq_pend[lane] = next | (next << 8) | 0x10000u;
+                        } else {
+                            fq_pend[lane] = next | (word & 0x1FF00u);
+                        }
+                    } else if constexpr (PACKL) {
                         fq_in[pos] = uint4{(unsigned)recq, (unsigned)(recq >> 32), term_id | ((unsigned)depth << 8),
                                            (unsigned)(stack.slot < 0 ? 0 : stack.slot)};
                         fq_in1[pos] = rec_w1[lane];
