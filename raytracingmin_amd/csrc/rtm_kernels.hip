@@ -1098,11 +1098,11 @@ static void launch_render_planes(const RenderParams& P_in, unsigned grid, hipStr
     const size_t tab = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + debug_lds_pad();
     constexpr size_t tag = SPLIT ? kFoldTagBytes : 0;
     if (P.max_bounces >= 0 && P.max_bounces <= 8) {
-        const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + tag);
+        const size_t lds = with_unit_table(P, tab + kFoldQueueBytesS + tag);
         render_tiles_kernel<MathFast, true, 8, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, true>
             <<<grid, 64, lds, stream>>>(P);
     } else {
-        const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL + tag);
+        const size_t lds = with_unit_table(P, tab + kFoldQueueBytesLS + tag);
         render_tiles_kernel<MathFast, true, 8, uint8_t, 0, 4, true, false, false, SPLIT, true, true, false, true>
             <<<grid, 64, lds, stream>>>(P);
     }
@@ -1120,7 +1120,7 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
         if (P.max_bounces >= 0 && P.max_bounces <= 8 && P.scene.n < 256) {  // ids and the identity index in a byte
             if constexpr (DEFER && UNROLL == -8) {
                 // scenes under 8 spheres (every shipped scene): the instantiation for exactly n spheres
-                const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
+                const size_t lds = with_unit_table(P, tab + kFoldQueueBytesS + (STEAL ? kStealLdsBytes : 0));
 #if RTM_OPT_AXIS
 #define RTM_AXIS_CASE(k, sig)                                                                                                  \
     if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && P.unit_tab == 1u) { /* rtm_path.h: sphere_disc */                        \
@@ -1143,7 +1143,7 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
                 }
             }
             if constexpr (DEFER) {
-                const size_t lds = with_unit_table(P, tab + kFoldQueueBytes + (STEAL ? kStealLdsBytes : 0));
+                const size_t lds = with_unit_table(P, tab + kFoldQueueBytesS + (STEAL ? kStealLdsBytes : 0));
                 render_tiles_kernel<M, LDS_TAB, UNROLL, RecT, 16, WPE, PARK, STAMP, true, SPLIT, true, false, false, false, STEAL>
                     <<<grid, 64, lds, stream>>>(P);
             } else {
@@ -1155,11 +1155,11 @@ static void launch_render_depth(const RenderParams& P_in, unsigned grid, hipStre
     }
     if constexpr (DEFER && sizeof(RecT) == 1) {
         if (P.scene.n < 256) {  // any depth: packed records + pooled stack, deferred fold
-            const size_t lds = with_unit_table(P, tab + kFoldQueueBytesL);  // (10 072 bytes for a 7-sphere scene: no room)
+            const size_t lds = with_unit_table(P, tab + kFoldQueueBytesLS);  // (8 280 bytes for a 7-sphere scene; 10 072 with the FIFO form: no room for the table then)
 #if RTM_OPT_AXIS
             if constexpr (UNROLL == -8) {
 #define RTM_AXIS_CASE(k, sig)                                                                                              \
-    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && P.unit_tab == 0u) { /* rtm_path.h: sphere_disc */                    \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && P.unit_tab == 1u) { /* rtm_path.h: sphere_disc */                    \
         render_tiles_kernel<M, LDS_TAB, axis_unroll(k, sig), RecT, 0, WPE, PARK, STAMP, false, SPLIT, true, true>           \
             <<<grid, 64, lds, stream>>>(P);                                                                                \
         return;                                                                                                            \

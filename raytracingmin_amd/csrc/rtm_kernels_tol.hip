@@ -33,7 +33,7 @@ template <int UNROLL, bool SPLIT>
 static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, hipStream_t stream) {
     RenderParams P = P_in;
     size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                 kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) /* prim_mask */ + lds_pad;
+                 kFoldQueueBytesS + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) /* prim_mask */ + lds_pad;
     // the near-unit Normalize table (rtm_device.h) where its 256 bytes do not cost a wave per CU
     P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
     if (P.unit_tab) lds += (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);
@@ -46,7 +46,7 @@ static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, 
 template <int UNROLL, bool SPLIT>
 static void launch_one_any(const RenderParams& P_in, unsigned grid, size_t lds_pad, hipStream_t stream) {
     RenderParams P = P_in;
-    size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + kFoldQueueBytesL + lds_pad;
+    size_t lds = lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) + kFoldQueueBytesLS + lds_pad;
     P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
     if (P.unit_tab) lds += (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);
     // <M, LDS_TAB, UNROLL, RecT, LDS_D, WPE, PARK, STAMP, PACK8, SPLIT, DEFER, PACKL>
@@ -56,8 +56,8 @@ template <bool SPLIT>
 static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, hipStream_t stream) {
 #if RTM_OPT_AXIS
     const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                                            kFoldQueueBytesL + lds_pad);  // (launch_one_any's rule: no room at 7 spheres)
-    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED && !table_fits) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
+                                            kFoldQueueBytesLS + lds_pad);  // (launch_one_any's rule)
+    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED && table_fits) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
         launch_one_any<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
         return;
     }
@@ -71,7 +71,7 @@ static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipSt
 #if RTM_OPT_AXIS
     // (the axis-signature instantiations take the near-unit Normalize table's presence as a compile-time fact: launch_one's rule)
     const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
-                                            kFoldQueueBytes + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) + lds_pad);
+                                            kFoldQueueBytesS + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) + lds_pad);
 #define RTM_AXIS_CASE(k, sig)                                                                   \
     if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && table_fits) { /* rtm_path.h: sphere_disc */ \
         launch_one<axis_unroll(k, sig), SPLIT>(P, grid, lds_pad, stream);                       \

@@ -251,8 +251,16 @@ __device__ __forceinline__ void store_pixel(const RenderParams& P, bool valid, i
 //           instead of C.  Same image, same counters (a reused primary hit still counts as the cast the reference
 //           performs); different work per sample than the reference, hence the label.
 constexpr int kFoldRing = 128;  // entries of the ring: < 64 waiting + <= 64 appended per iteration
-constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;
+constexpr size_t kFoldQueueBytes = kFoldRing * 16 + 3 * 64 * 8 + 64 * 8 + 64 * 4;  // the FIFO form: ring, terms, FIFO, counts
 constexpr size_t kFoldQueueBytesL = kFoldQueueBytes + kFoldRing * 8 + 64 * 8;  // + word 1 of the entries and of the lanes
+#ifndef RTM_OPT_SCATTER
+#define RTM_OPT_SCATTER 1  // the folding lane adds its term to the entry's pixel (render_tiles_kernel: kScatter; A/B switch)
+#endif
+// kScatter kernels (every deferred-fold kernel but the primary-hit-reuse row): no staged terms, no FIFO — ring, the pixels'
+// counts of added entries (a small wave's tags in their place), the lanes' counts: 1 792 bytes less per wave, which is what lets
+// the any-depth kernels keep the near-unit Normalize table at 16 waves per CU
+constexpr size_t kFoldQueueBytesS = RTM_OPT_SCATTER ? kFoldRing * 16 + 64 * 4 + 64 * 4 : kFoldQueueBytes;
+constexpr size_t kFoldQueueBytesLS = RTM_OPT_SCATTER ? kFoldQueueBytesS + kFoldRing * 8 + 64 * 8 : kFoldQueueBytesL;
 // (SPLIT: a small wave's ring entries carry a 2-byte tag (owner lane, sample).  The tags live in the per-lane FIFO array,
 // which a small wave does not use: 256 of its 512 bytes.  A separate array put the any-depth kernel at 10 328 bytes of LDS per
 // wave — 15 instead of 16 waves per CU, 5 % on every unlimited-depth frame, profiles/r3/ab_r2_vs_r3.txt.)
@@ -293,25 +301,28 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     double* cam = reinterpret_cast<double*>(lds_raw + (LDS_TAB ? lds_table_bytes(scene_n) : 0));
     double* trig = cam + 10;                 // 9 camera doubles + pad
     // the shading constants: sincos and — where the launcher found the LDS for it — the near-unit Normalize table
-    // wave-uniform; the axis-signature instantiations are launched only when the table's presence is what their flavour implies
-    // (depth-capped: there; any depth: not there — the launchers check), so it is a compile-time constant for them
+    // wave-uniform; the axis-signature instantiations are launched only when the table is there (the launchers check), so it is
+    // a compile-time constant for them
 #ifndef RTM_OPT_CTTAB
 #define RTM_OPT_CTTAB 1  // (A/B switch)
 #endif
-    const bool unit_tab = (RTM_OPT_CTTAB && UNROLL <= -1000) ? PACK8 : (P.unit_tab != 0u);
+    const bool unit_tab = (RTM_OPT_CTTAB && UNROLL <= -1000) ? true : (P.unit_tab != 0u);
     double* park = trig + (unit_tab ? kShadeConstCount : kTrigConstCount);
     const ShadeLds shade_lds(trig, unit_tab);
     RecT* rec = reinterpret_cast<RecT*>(park + (PARK ? 6 * 64 : 0));
-    // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]
+    // DEFER: [ring 128 x uint4][terms 3 x 64 doubles][per-lane FIFO of ring positions][per-lane count]; kScatter (below):
+    // [ring][per pixel: entries added so far, 64 words — a small wave's 128 two-byte tags in their place][per-lane count]
+    constexpr bool kScatter = (RTM_OPT_SCATTER != 0) && DEFER && (PACK8 || PACKL) && !REUSE;
     uint4* fq_in = reinterpret_cast<uint4*>(park + 6 * 64);
-    double* fq_out = reinterpret_cast<double*>(fq_in + kFoldRing);
-    unsigned long long* fq_fifo = reinterpret_cast<unsigned long long*>(fq_out + 3 * 64);
-    unsigned* fq_pend = reinterpret_cast<unsigned*>(fq_fifo + 64);
+    double* fq_out = reinterpret_cast<double*>(fq_in + kFoldRing);  // (the FIFO form only)
+    unsigned long long* fq_fifo = kScatter ? reinterpret_cast<unsigned long long*>(fq_in + kFoldRing)
+                                           : reinterpret_cast<unsigned long long*>(fq_out + 3 * 64);
+    unsigned* fq_pend = kScatter ? reinterpret_cast<unsigned*>(fq_fifo) + 64 : reinterpret_cast<unsigned*>(fq_fifo + 64);
     unsigned long long* fq_in1 = reinterpret_cast<unsigned long long*>(fq_pend + 64);  // PACKL: word 1 of the entries
     unsigned long long* rec_w1 = fq_in1 + kFoldRing;                                   // PACKL: word 1 of the lanes
     // SPLIT, small waves only: tag of every ring entry, in the FIFO array they have no other use for
     unsigned short* fq_tag = reinterpret_cast<unsigned short*>(fq_fifo);
-    static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned long long), "the tags fit the FIFO array");
+    static_assert(kFoldRing * sizeof(unsigned short) <= 64 * sizeof(unsigned), "the tags fit the FIFO array, and the counts' that takes its place");
     // Who adds a folded term to its pixel (fold_pass).  Round 1's form: the OWNER finds its entries through a per-lane FIFO of
     // ring positions and reads the terms back from LDS — as many rounds as the busiest pixel has entries in the pass, each with
     // the FIFO's decoding (23 vector instructions and 10 LDS operations a round, ~4.5 rounds a pass).  kScatter (round 4, the
@@ -320,13 +331,9 @@ __global__ __launch_bounds__(64, WPE) void render_tiles_kernel(const RenderParam
     // entries already added (fq_done) — straight from its registers: a compare, three LDS read-add-writes and the count per
     // round, no FIFO, no term staging, and no forced passes (a FIFO held 8 positions).  The order of a pixel's additions is the
     // order of its path ends either way.
-#ifndef RTM_OPT_SCATTER
-#define RTM_OPT_SCATTER 1
-#endif
     // (PACKL, the any-depth kernels: owner and count ride in the entry's third word above term id and depth, and the lane's
     // "may a deep entry of mine still be waiting" is the count it had after its last deep path against fq_done — fq_pend bits
     // 8..15 and 16)
-    constexpr bool kScatter = (RTM_OPT_SCATTER != 0) && DEFER && (PACK8 || PACKL) && !REUSE;
     unsigned* fq_done = reinterpret_cast<unsigned*>(fq_fifo);  // kScatter: per lane, entries of its pixel added so far (the FIFO's place)
     if constexpr (DEFER) fq_pend[lane] = 0u;  // entries waiting (FIFO form) / path ends so far (kScatter)
     if constexpr (kScatter) fq_done[lane] = 0u;
