@@ -50,9 +50,7 @@ __device__ __forceinline__ unsigned grid_tile_of_block(const RenderParams& P, un
 // blockIdx.x: index into this launch's tiles [tile_base, tile_base + gridDim.x); terms: P.contrib, gridDim.x tiles
 //   COUNT   (RTM_MODE_COUNT_TESTS) the walks count their Intersect evaluations into P.counters[4]: the measurement
 //           bench.py's rows of this kernel carry (sphere tests per cast); the timed steps run the plain instantiation
-//   SPHERES the scene holds no png::PlaneObject (the launcher checks P.scene.plane): the per-object "is it a plane" tests of the
-//           walk's set-up and of the shading block are compiled out
-template <typename RecT, int LDS_D, bool COUNT = false, bool SPHERES = false>
+template <typename RecT, int LDS_D, bool COUNT = false>
 __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(const RenderParams P, const unsigned tile_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int lane = threadIdx.x;
@@ -73,8 +71,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
     if (lane == 0) *next_unit = 0u;
     __syncthreads();
 
-    using Scene = typename std::conditional<SPHERES, SceneGlobalSpheres, SceneGlobal>::type;
-    Scene sc;
+    SceneGlobal sc;
     sc.v = P.scene;
     const unsigned local_tile = grid_tile_of_block(P, blockIdx.x);
     const unsigned tile = tile_base + local_tile;
@@ -113,7 +110,7 @@ __global__ __launch_bounds__(64, kGridWavesPerSimd) void render_grid_kernel(cons
         return true;
     };
     bool busy = take_unit();
-    GridWalk<MathFast, Scene, COUNT> walk;
+    GridWalk<MathFast, SceneGlobal, COUNT> walk;
     walk.attach_queue(queue, 64, lane);
     bool walking = false;
     [[maybe_unused]] unsigned long long n_tests = 0;

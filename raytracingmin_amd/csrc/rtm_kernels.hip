@@ -1787,13 +1787,7 @@ static void launch_grid_kernel(const RenderParams& P, unsigned base, unsigned cn
         if (deep) render_grid_kernel<uint32_t, 32, true><<<cnt, 64, lds, stream>>>(P, base);
         else render_grid_kernel<uint32_t, 16, true><<<cnt, 64, lds, stream>>>(P, base);
     } else {
-#ifndef RTM_OPT_GRID_SPHERES
-#define RTM_OPT_GRID_SPHERES 1  // (A/B switch)
-#endif
-        if (RTM_OPT_GRID_SPHERES && P.scene.plane == nullptr) {  // (no png::PlaneObject among the objects: the plane tests compiled out)
-            if (deep) render_grid_kernel<uint32_t, 32, false, true><<<cnt, 64, lds, stream>>>(P, base);
-            else render_grid_kernel<uint32_t, 16, false, true><<<cnt, 64, lds, stream>>>(P, base);
-        } else if (deep) render_grid_kernel<uint32_t, 32, false><<<cnt, 64, lds, stream>>>(P, base);
+        if (deep) render_grid_kernel<uint32_t, 32, false><<<cnt, 64, lds, stream>>>(P, base);
         else render_grid_kernel<uint32_t, 16, false><<<cnt, 64, lds, stream>>>(P, base);
     }
 }

@@ -653,12 +653,6 @@ struct SceneGlobal {
     }
 };
 
-// SceneGlobal for launches whose scene holds no png::PlaneObject (the grid kernel's common case): v.plane is null by the
-// launcher's word, so every "is object i a plane" test is compiled out
-struct SceneGlobalSpheres : SceneGlobal {
-    static constexpr bool kNeverPlanes = true;
-};
-
 // Small scenes: geometry still arrives through wave-uniform (scalar) loads, but the per-lane
 // look-ups (hit sphere's centre, kd, emission, colorKD) come from an LDS copy of the tables.
 struct SceneLds {
@@ -1211,7 +1205,7 @@ struct GridWalk {
         for (int k = 0; k < n_big; ++k) {  // the objects every ray tests: spheres that span the scene, and planes
             const int i = __builtin_amdgcn_readfirstlane(big[k]);
             const double4 g = sc.geom_uniform(i);
-            if (!Scene::kNeverPlanes && sc.v.plane != nullptr && __double2hiint(g.w) < 0)  // wave-uniform: object i is a png::PlaneObject
+            if (sc.v.plane != nullptr && __double2hiint(g.w) < 0)  // wave-uniform: object i is a png::PlaneObject
                 consider_plane(sc.v.plane + (size_t)i * 16, i, org, dir);
             else
                 consider(i, g, org, dir);
@@ -1256,7 +1250,7 @@ struct GridWalk {
             for (int i = 0; i < n; ++i) {
                 const double4 g = sc.geom_uniform(i);
                 if (!exhaustive) continue;
-                if (!Scene::kNeverPlanes && sc.v.plane != nullptr && __double2hiint(g.w) < 0) {  // (in the big list too: tested twice, same result)
+                if (sc.v.plane != nullptr && __double2hiint(g.w) < 0) {  // (in the big list too: tested twice, same result)
                     consider_plane(sc.v.plane + (size_t)i * 16, i, org, dir);
                     continue;
                 }
