@@ -37,6 +37,9 @@ __device__ __forceinline__ D3 fold_step(const D3 c, const D3 L, const D3 e) {
 #pragma clang fp contract(off)
     return D3{c.x * L.x + e.x, c.y * L.y + e.y, c.z * L.z + e.z};
 }
+// ... and the same level where the emission added is known to be (+0, +0, +0) and the product cannot be -0 (SceneView::
+// fold_flags, kFoldNoLevelEmission): x + (+0) == x bit for bit for every x but -0, so the addition is left out
+__device__ __forceinline__ D3 fold_step_mul(const D3 c, const D3 L) { return D3{c.x * L.x, c.y * L.y, c.z * L.z}; }
 // src/Ray.h:61-63
 __device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // src/Ray.h:64-66 (middle component is (-a.x)*b.z + a.z*b.x)

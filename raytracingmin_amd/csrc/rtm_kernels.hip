@@ -127,6 +127,20 @@ static uint64_t axis_pattern(const double* geom, size_t n) {
     return pat;
 }
 
+// SceneView::fold_flags from flattened material rows (colorKD[3], emission[3], kd, kd * 2^24): see kFoldNoLevelEmission
+static unsigned fold_flags_of(const double* mat, size_t n) {
+    auto plain = [](double v) { return !std::signbit(v) && !std::isnan(v); };  // +0 or positive (or +inf)
+    for (size_t i = 0; i < n; ++i) {
+        const double* m = mat + i * 8;
+        if (!(plain(m[3]) && plain(m[4]) && plain(m[5]))) return 0u;  // a path may END on any object: L starts as its emission
+        if (m[6] > 0.0) {  // a path can bounce off this one (the roulette passes only for a draw <= kd, and draws are > 0)
+            if (!(m[3] == 0.0 && m[4] == 0.0 && m[5] == 0.0)) return 0u;
+            if (!(plain(m[0]) && plain(m[1]) && plain(m[2]))) return 0u;
+        }
+    }
+    return kFoldNoLevelEmission;
+}
+
 __global__ void flatten_scene_kernel(const rtm_sphere* __restrict__ sp, size_t n,
                                      double* __restrict__ geom, double* __restrict__ mat, double* __restrict__ surf = nullptr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +289,7 @@ struct rtm_scene {
     rtm::GridHeader grid_hdr;           // host copy (grid_for: is the camera within the pads' reach?)
     bool grid_far_bounces = false;      // a diffuse sphere encloses the gridded ones from beyond the pads' reach (build_scene_grid)
     bool has_planes = false;
+    unsigned fold_flags = 0;            // SceneView::fold_flags (fold_flags_of)
     uint64_t axis_pat = 0;              // SceneView::axis_pat: which of the first 32 spheres sit on a coordinate axis (axis_pattern)
     uint64_t content_hash = 0;            // cache entries only ...
     std::vector<unsigned char> content;   // ... and the bytes the hash was taken of (compared on a hash hit)
@@ -310,9 +325,10 @@ static int launch_scene_aux(const double* geom, size_t n, double* aux, hipStream
 }
 static SceneView scene_view(const double* geom, const double* mat, const double* aux, size_t n,
                             const double* plane = nullptr, const void* grid = nullptr, const double* surf = nullptr,
-                            uint64_t axis_pat = 0) {
+                            uint64_t axis_pat = 0, unsigned fold_flags = 0) {
     SceneView v{(const double4*)geom, mat, (int)n};
     v.axis_pat = axis_pat;
+    v.fold_flags = fold_flags;
     v.plane = plane;
     v.surf = surf;
     v.grid = static_cast<const GridHeader*>(grid);
@@ -614,6 +630,7 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     std::vector<double> hg, hm, hs;
     flatten_scene(sp, n, hg, hm, &hs);
     sc.axis_pat = axis_pattern(hg.data(), n);
+    sc.fold_flags = fold_flags_of(hm.data(), n);
     int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
@@ -646,6 +663,9 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
         std::vector<double> rows(n * 4);
         RTM_HIP_CHECK(hipMemcpy(rows.data(), sc.geom.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
         sc.axis_pat = axis_pattern(rows.data(), n);
+        std::vector<double> mrows((n + 1) * 8);
+        RTM_HIP_CHECK(hipMemcpy(mrows.data(), sc.mat.p, mrows.size() * sizeof(double), hipMemcpyDeviceToHost));
+        sc.fold_flags = fold_flags_of(mrows.data(), n);
     }
     if (n < kGridMinSpheres) return RTM_OK;
     std::vector<double> hg(n * 4);  // the grid is built on the host: the geometry rows come back once
@@ -2271,7 +2291,7 @@ int scratch_bytes(const rtm_settings* st, const rtm_scene* scene, const rtm_opti
     RenderParams P;
     RenderPlan plan;
     const SceneView view = scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat);
+                                      scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat, scene->fold_flags);
     for (int k = 0; k < 6; ++k) out[k] = 0;
     if (output_rows(opt) == 0) return RTM_OK;
     rc = plan_render(st, view, scene->n, opt, P, plan);
@@ -2301,7 +2321,7 @@ int render_scene(const rtm_settings* st, const rtm_scene* scene, const rtm_optio
     std::shared_lock<std::shared_mutex> gate(g_gate);
     reap_scenes(false);
     rc = render_view(st, scene_view(scene->geom.as<double>(), scene->mat.as<double>(), scene->aux.as<double>(), scene->n,
-                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat),
+                                    scene->has_planes ? scene->plane.as<double>() : nullptr, grid_for(scene, st, opt), scene->surf.as<double>(), scene->axis_pat, scene->fold_flags),
                      scene->n, opt, out64, out32, out8, (hipStream_t)stream_v, stats);
     note_scene_use(scene, (hipStream_t)stream_v);  // also after a failure: part of the work may have been queued
     return rc;
@@ -2319,7 +2339,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_scene(sp, n, opt->device, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat, sc->fold_flags),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);  // an eviction while this render is queued parks the tables instead of waiting
         return rc;
@@ -2333,7 +2353,7 @@ int render_device(const rtm_settings* st, const rtm_sphere* sp, size_t n, int on
         std::shared_ptr<rtm_scene> sc;
         rc = cached_device_scene(sp, n, opt->device, stream, &sc);
         if (rc != RTM_OK) return rc;
-        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat),
+        rc = render_view(st, scene_view(sc->geom.as<double>(), sc->mat.as<double>(), sc->aux.as<double>(), n, nullptr, grid_for(sc.get(), st, opt), sc->surf.as<double>(), sc->axis_pat, sc->fold_flags),
                          n, opt, out64, out32, out8, stream, stats);
         note_scene_use(sc.get(), stream);
         return rc;

@@ -27,6 +27,9 @@
 #ifndef RTM_OPT_CTMODE
 #define RTM_OPT_CTMODE 1  // what an instantiation knows at compile time: its mode (axis signatures), "no planes" (SceneLds) ...
 #endif
+#ifndef RTM_OPT_FOLDMUL
+#define RTM_OPT_FOLDMUL 1  // the packed folds leave a bounce level's "+ (+0, +0, +0)" out (SceneView::fold_flags; A/B switch)
+#endif
 #ifndef RTM_OPT_CTN
 #define RTM_OPT_CTN 0     // ... and (NOT kept: profiles/r4/ctn_ab.txt — nothing for the tolerance row, +3 % for the exact kernel,
 #endif                    // whose register allocation it upsets) its sphere count in the exact-n instantiations; A/B switches
@@ -571,7 +574,13 @@ struct SceneView {
     // chunked search of the LDS-table kernels evaluates such a sphere's discriminant from per-ray shared products
     // (sphere_disc below): the reference's own roundings, fewer instructions.
     unsigned long long axis_pat = 0ull;
+    // kFoldNoLevelEmission (set by the host where it holds the material rows, else 0): every object a path can bounce off
+    // (kd > 0) has emission (+0, +0, +0) and a colorKD without sign bits, and no emission has a sign bit — the fold's
+    // "+ emission" of a bounce level (src/Renderer.cpp:109) then adds +0 to a product that is never -0: an identity, bit for
+    // bit, which the packed folds leave out (and with it the levels' emission reads).  The shipped Cornell box: the walls.
+    unsigned fold_flags = 0u;
 };
+constexpr unsigned kFoldNoLevelEmission = 1u;
 
 // png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line
 // (src/SettingData.cpp:244), the sphere's near threshold, then the square's extent.
@@ -1884,6 +1893,20 @@ template <class Scene>
 __device__ __forceinline__ D3 path_fold_packed8_all(const Scene& sc, const int term_id, const unsigned long long rec) {
     D3 L = sc.emission(term_id);
     const unsigned lo = (unsigned)rec, hi = (unsigned)(rec >> 32);
+#if RTM_OPT_FOLDMUL
+    if (sc.v.fold_flags & kFoldNoLevelEmission) {  // wave-uniform: a bounce level adds (+0, +0, +0) — SceneView::fold_flags
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned word = g ? hi : lo;
+            D3 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = sc.color_kd((int)((word >> (8 * k)) & 0xFFu));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) L = fold_step_mul(c[k], L);
+        }
+        return L;
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const unsigned word = g ? hi : lo;
@@ -1917,6 +1940,19 @@ __device__ __forceinline__ D3 path_fold_packed16(const Scene& sc, const int term
     }
     auto word = [&](const unsigned long long w) {
         const unsigned half[2] = {(unsigned)(w >> 32), (unsigned)w};  // levels 7..4, then 3..0
+#if RTM_OPT_FOLDMUL
+        if (sc.v.fold_flags & kFoldNoLevelEmission) {  // wave-uniform: a bounce level adds (+0, +0, +0)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                D3 c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k] = sc.color_kd((int)((half[g] >> (8 * (3 - k))) & 0xFFu));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) L = fold_step_mul(c[k], L);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             D3 c[4], e[4];
