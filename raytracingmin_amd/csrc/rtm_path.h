@@ -1634,8 +1634,17 @@ __device__ __forceinline__ void path_bounce_core(MI& m, const Scene& sc, const i
         }
     }
     // :82-83  w = Dot(n, d) < 0 ? n : n * -1.0  (multiplying by -1.0 flips the sign bit, exactly)
-    const LaneMask flip = lane_mask(!(dot(normal, dir) < 0.0));
-    const D3 w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
+#ifndef RTM_OPT_NOFLIP
+#define RTM_OPT_NOFLIP 1  // (A/B switch)
+#endif
+    const bool turn = !(dot(normal, dir) < 0.0);
+    D3 w = normal;
+    // (a sphere hit from outside — every hit in a room seen from inside — never turns its normal: one scalar test for the wave,
+    // and the mask and the three sign flips are skipped)
+    if (!RTM_OPT_NOFLIP || __builtin_amdgcn_ballot_w64(turn) != 0) {
+        const LaneMask flip = lane_mask(turn);
+        w = d3(negate_where(flip, normal.x), negate_where(flip, normal.y), negate_where(flip, normal.z));
+    }
     out.draws = 3;
     // :88 r1 = 2 PI u with u = m * 2^-24: (2 PI * 2^-24) * m is the same correctly rounded product as 2 PI * (m * 2^-24)
     const double m24 = rng_next_m(rng);  // (r1 is formed where its sin / cos are taken: sincos_draw)
