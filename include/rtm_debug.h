@@ -46,6 +46,12 @@ int rtm_debug_grid_nearest(const rtm_sphere* spheres, size_t n, const double* or
  * (info is filled: call once without buffers for the sizes). */
 int rtm_debug_grid_build(const rtm_sphere* spheres, size_t n, uint64_t* info, double* pads, uint32_t* ranges, size_t ranges_cap,
                          uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap);
+/* What the host finds in a sphere array when it flattens it into the kernels' tables, on the HOST (no device is touched; runs in
+ * the CPU test suite): facts[0] = two bits per sphere for the first 32 — 1 / 2 / 3: the centre's only coordinate that is not
+ * +-0 is x / y / z (the axis-signature instantiations of the exact-n kernels, csrc/rtm_path.h: sphere_disc) —, facts[1] bit 0:
+ * every object a path can bounce off (kd > 0) emits (+0, +0, +0) and no colorKD or emission carries a sign bit (the packed
+ * folds then leave a bounce level's "+ emission" out: SceneView::fold_flags). */
+int rtm_debug_scene_facts(const rtm_sphere* spheres, size_t n, uint64_t facts[2]);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */
 int rtm_debug_component_bench(int which, const rtm_sphere* spheres, size_t n, int reps, int blocks, int lds_pad,
                               double* cycles_per_rep);

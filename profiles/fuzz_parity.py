@@ -33,6 +33,8 @@ def sphere(pos, r, col):
 bad = 0
 tol_cases = tol_out = tol_differ = 0
 for case in range(cases):
+    if case and case % 500 == 0:  # (a long run must not look hung: one line per 500 frames)
+        print("...", case, "frames so far,", bad, "differ", flush=True)
     n = int(rng.choice([1, 2, 5, 7, 7, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 33, 64, 100, 254, 255, 256, 257, 400, 511, 512,
                         513, 1000, 2500]))
     kind = case % 4

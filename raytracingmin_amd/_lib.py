@@ -126,6 +126,7 @@ DEBUG_SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "rtm_debug_grid_nearest": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rtm_debug_scene_facts": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "rtm_debug_grid_build": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t]),
     "rtm_debug_component_bench": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,

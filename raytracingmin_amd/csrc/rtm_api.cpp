@@ -132,6 +132,7 @@ int rtm_debug_grid_build(const rtm_sphere* sp, size_t n, uint64_t* info, double*
                          uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap) {
     RTM_GUARD(rtm::grid_build_host(sp, n, info, pads, ranges, ranges_cap, items, items_cap, big, big_cap))
 }
+int rtm_debug_scene_facts(const rtm_sphere* sp, size_t n, uint64_t facts[2]) { RTM_GUARD(rtm::scene_facts_host(sp, n, facts)) }
 int rtm_debug_fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms) {
     RTM_GUARD(rtm::fp64_peak(waves_per_simd, min_ms, tflops, kernel_ms))
 }

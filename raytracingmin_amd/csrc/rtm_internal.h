@@ -53,6 +53,7 @@ int component_bench(int which, const rtm_sphere* sp, size_t n, int reps, int blo
 int selfcheck(int kind, unsigned long long* mismatches);
 int grid_nearest_probe(const rtm_sphere* sp, size_t n, const double* org, const double* dir, size_t n_rays, int32_t* out_id,
                        double* out_t, uint32_t* out_tests, uint32_t* out_steps, uint64_t* info);
+int scene_facts_host(const rtm_sphere* sp, size_t n, uint64_t* facts);
 int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads, uint32_t* ranges, size_t ranges_cap,
                     uint32_t* items, size_t items_cap, int32_t* big, size_t big_cap);
 int fp64_peak(int waves_per_simd, double min_ms, double* tflops, double* kernel_ms);

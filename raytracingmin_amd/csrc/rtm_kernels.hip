@@ -552,6 +552,16 @@ int grid_build_host(const rtm_sphere* sp, size_t n, uint64_t* info, double* pads
     return RTM_OK;
 }
 
+// rtm_debug_scene_facts: axis_pattern and fold_flags_of on the HOST, from the caller's spheres (tests/test_host_io.py)
+int scene_facts_host(const rtm_sphere* sp, size_t n, uint64_t* facts) {
+    if ((!sp && n) || !facts) return RTM_ERR_INVALID_ARGUMENT;
+    std::vector<double> hg, hm;
+    flatten_scene(sp, n, hg, hm);
+    facts[0] = axis_pattern(hg.data(), n);
+    facts[1] = fold_flags_of(hm.data(), n);
+    return RTM_OK;
+}
+
 // Build + upload; a scene that gets no grid keeps sc.grid empty (not an error).  `hg`: the host copy of the geometry rows.
 // `hm`: the material rows (kd in column 6), or null.
 static int build_scene_grid(rtm_scene& sc, const double* hg, const double* hm, size_t n, int device,

@@ -321,3 +321,43 @@ def test_scene_edit_epoch_counts_scene_edits_only():
     before = edit_epoch()
     loaded.object.pop()
     assert edit_epoch() > before  # the loader's list is the tracking kind too
+
+
+def _facts(objs):
+    from raytracingmin_amd import Camera, SettingData, vec3
+    data = SettingData(width=8, height=8, samples=1, superSamples=1, camera=Camera(vec3(0, 0, -10), vec3(0, 0, 0), vec3(0, 1, 0), 2.0),
+                       object=objs)
+    _, arr, n = data.to_c()
+    out = (C.c_uint64 * 2)()
+    _lib.check(_lib.lib().rtm_debug_scene_facts(arr, n, out), "scene facts")
+    return int(out[0]), int(out[1])
+
+
+def test_scene_facts_the_host_finds_when_it_flattens_a_scene():
+    """Host logic behind two kernel specialisations (no device): SceneView::axis_pat — which spheres sit on a coordinate axis; the
+    shipped Cornell box's signature selects the axis-signature instantiation — and SceneView::fold_flags — a bounce level's
+    "+ emission" is an identity where nothing a path can bounce off emits and nothing carries a sign bit."""
+    import raytracingmin_amd as rtm
+    from raytracingmin_amd import Material, SphereObject, vec3
+    cornell = 2 | (1 << 2) | (1 << 4) | (2 << 6) | (2 << 8) | (3 << 10) | (3 << 12)
+    scenes = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
+    box = rtm.LoadData(os.path.join(scenes, "cornellBoxSetting.json")).data
+    assert _facts(list(box.object)) == (cornell, 1)
+    assert _facts(list(rtm.LoadData(os.path.join(scenes, "simpleSetting1.json")).data.object))[0] == (1 << 2) | (1 << 4) | (2 << 6) | (2 << 8)
+    assert _facts(list(rtm.LoadData(os.path.join(scenes, "settingData.json")).data.object))[0] == 2 | (1 << 4)
+
+    def s(pos, col=(.5, .5, .5), em=(0, 0, 0)):
+        return SphereObject(vec3(*pos), 1.0, Material(vec3(*col), vec3(*em)))
+    # patterns: x, y, z, the origin, two non-zero coordinates, a negative zero counts as zero, a denormal does not, NaN / inf: none
+    pat, _ = _facts([s((3, 0, 0)), s((0, -2, 0)), s((0, 0, 1e-300)), s((0, 0, 0)), s((1, 1, 0)), s((-0.0, 5, -0.0)), s((5e-324, 5, 0)),
+                     s((float("nan"), 0, 0)), s((float("inf"), 0, 0))])
+    assert [(pat >> (2 * i)) & 3 for i in range(9)] == [1, 2, 3, 0, 0, 2, 0, 0, 0]
+    assert _facts([s((1, 0, 0))] * 40)[0] == int("01" * 32, 2)  # the first 32 spheres only
+    # fold flags: on for diffuse non-emitters + black emitters; off for a diffuse emitter, a negative or -0 colour or emission
+    light = s((0, 9, 0), col=(0, 0, 0), em=(5, 5, 5))
+    assert _facts([light, s((1, 0, 0))])[1] == 1
+    assert _facts([light, s((1, 0, 0), em=(0, 0.1, 0))])[1] == 0       # a diffuse emitter: its level adds something
+    assert _facts([light, s((1, 0, 0), col=(.5, -.2, .5))])[1] == 0     # a negative colour: a product may be -0 ... or negative
+    assert _facts([light, s((1, 0, 0), em=(0, -0.0, 0))])[1] == 0       # (x + -0 is an identity too, but the rule keeps to +0)
+    assert _facts([s((0, 9, 0), col=(0, 0, 0), em=(5, -1, 5)), s((1, 0, 0))])[1] == 0  # a path may END anywhere: no negative start
+    assert _facts([])[1] == 1 and _facts([])[0] == 0
