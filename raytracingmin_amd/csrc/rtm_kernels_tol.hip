@@ -29,6 +29,9 @@
 
 namespace rtm_tol {
 
+#ifndef RTM_TOL_WPE
+#define RTM_TOL_WPE 4  // waves per SIMD of the depth-capped kernel's launch bound (A/B knob: profiles/r4/tol_wpe_ab.txt)
+#endif
 template <int UNROLL, bool SPLIT>
 static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, hipStream_t stream) {
     RenderParams P = P_in;
@@ -38,7 +41,7 @@ static void launch_one(const RenderParams& P_in, unsigned grid, size_t lds_pad, 
     P.unit_tab = unit_table_fits(lds) ? 1u : 0u;
     if (P.unit_tab) lds += (size_t)(kShadeConstCount - kTrigConstCount) * sizeof(double);
     // <M, LDS_TAB, UNROLL, RecT, LDS_D, WPE, PARK, STAMP, PACK8, SPLIT, DEFER, PACKL, REUSE, PLANES, STEAL>
-    render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 16, 4, true, false, true, SPLIT, true, false, false, false, true>
+    render_tiles_kernel<MathFast, true, UNROLL, uint8_t, 16, RTM_TOL_WPE, true, false, true, SPLIT, true, false, false, false, true>
         <<<grid, 64, lds, stream>>>(P);
 }
 // Any depth (max_bounces < 0 — the reference's own semantics — or > 8): the deferred fold with records packed by position
