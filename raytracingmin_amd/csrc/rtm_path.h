@@ -965,14 +965,18 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
         double b[K], D4[K], sq[K];
         if constexpr (SIG != 0u) {  // the scene's axis signature is a compile-time constant: sphere_disc's branches fold
             const AxisShared A(org, dir);
+#ifndef RTM_AXIS_PHASE
+#define RTM_AXIS_PHASE 2  // spheres whose geometry is fetched together in the axis form (A/B knob; an axis sphere needs 4 SGPRs, not 8)
+#endif
+            constexpr int PA = RTM_AXIS_PHASE;
 #pragma unroll
-            for (int k0 = 0; k0 < K; k0 += PH) {
-                double4 g[PH];
+            for (int k0 = 0; k0 < K; k0 += PA) {
+                double4 g[PA];
 #pragma unroll
-                for (int k = 0; k < PH; ++k)
+                for (int k = 0; k < PA; ++k)
                     if (k0 + k < K) g[k] = sc.geom_uniform(i0 + k0 + k);
 #pragma unroll
-                for (int k = 0; k < PH; ++k)
+                for (int k = 0; k < PA; ++k)
                     if (k0 + k < K) sphere_disc(g[k], (SIG >> (2 * (k0 + k))) & 3u, org, dir, A, b[k0 + k], D4[k0 + k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
