@@ -16,7 +16,7 @@ extern "C" {
 #endif
 
 /* device sqrt / sqrtf / division / sin / cos and the exact-fast forms on caller data; `op` as in
- * math_probe_kernel (csrc/rtm_seam_kernels.h); ops 32..40: the tolerance row's arithmetic — one-ulp square root, division and
+ * math_probe_kernel (csrc/rtm_seam_kernels.h); ops 32..41: the tolerance row's arithmetic — one-ulp square root, division and
  * reciprocal, a contracted multiply-add, its sin / cos, the unfused fold step (csrc/rtm_kernels_tol.hip) */
 int rtm_debug_math_probe(int op, const double* a, const double* b, size_t n, double* out);
 /* exhaustive device self-checks; *mismatches = number of failing inputs (kind 0: fast sqrtf) */
@@ -50,7 +50,8 @@ int rtm_debug_grid_build(const rtm_sphere* spheres, size_t n, uint64_t* info, do
  * the CPU test suite): facts[0] = two bits per sphere for the first 32 — 1 / 2 / 3: the centre's only coordinate that is not
  * +-0 is x / y / z (the axis-signature instantiations of the exact-n kernels, csrc/rtm_path.h: sphere_disc) —, facts[1] bit 0:
  * every object a path can bounce off (kd > 0) emits (+0, +0, +0) and no colorKD or emission carries a sign bit (the packed
- * folds then leave a bounce level's "+ emission" out: SceneView::fold_flags). */
+ * folds then leave a bounce level's "+ emission" out: SceneView::fold_flags), bit 1: every |centre| + radius is at most 1e7 (a
+ * compact scene: the tolerance row's search may take its square roots without the residual step). */
 int rtm_debug_scene_facts(const rtm_sphere* spheres, size_t n, uint64_t facts[2]);
 /* isolated nearest-hit / shading loops timed with s_memtime (profiles/component_bench.py) */
 int rtm_debug_component_bench(int which, const rtm_sphere* spheres, size_t n, int reps, int blocks, int lds_pad,

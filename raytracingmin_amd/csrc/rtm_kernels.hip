@@ -128,6 +128,15 @@ static uint64_t axis_pattern(const double* geom, size_t n) {
 }
 
 // SceneView::fold_flags from flattened material rows (colorKD[3], emission[3], kd, kd * 2^24): see kFoldNoLevelEmission
+// kSceneCompact from flattened geometry rows (cx, cy, cz, r*r): every sphere within kCompactExtent of the origin
+static unsigned compact_flag_of(const double* geom, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const double* g = geom + i * 4;
+        const double reach = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) + std::sqrt(std::fabs(g[3]));
+        if (!(reach <= kCompactExtent)) return 0u;  // (NaN fails too)
+    }
+    return kSceneCompact;
+}
 static unsigned fold_flags_of(const double* mat, size_t n) {
     auto plain = [](double v) { return !std::signbit(v) && !std::isnan(v); };  // +0 or positive (or +inf)
     for (size_t i = 0; i < n; ++i) {
@@ -558,7 +567,7 @@ int scene_facts_host(const rtm_sphere* sp, size_t n, uint64_t* facts) {
     std::vector<double> hg, hm;
     flatten_scene(sp, n, hg, hm);
     facts[0] = axis_pattern(hg.data(), n);
-    facts[1] = fold_flags_of(hm.data(), n);
+    facts[1] = fold_flags_of(hm.data(), n) | compact_flag_of(hg.data(), n);
     return RTM_OK;
 }
 
@@ -640,7 +649,7 @@ static int scene_build_host(rtm_scene& sc, const rtm_sphere* sp, size_t n, int d
     std::vector<double> hg, hm, hs;
     flatten_scene(sp, n, hg, hm, &hs);
     sc.axis_pat = axis_pattern(hg.data(), n);
-    sc.fold_flags = fold_flags_of(hm.data(), n);
+    sc.fold_flags = fold_flags_of(hm.data(), n) | compact_flag_of(hg.data(), n);
     int rc = sc.geom.alloc_pooled((n ? n : 1) * 4 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.mat.alloc_pooled((n + 1) * 8 * sizeof(double), device);
     if (rc == RTM_OK) rc = sc.aux.alloc_pooled(scene_aux_doubles(n) * sizeof(double), device);
@@ -675,7 +684,7 @@ static int scene_build_device(rtm_scene& sc, const rtm_sphere* sp_dev, size_t n,
         sc.axis_pat = axis_pattern(rows.data(), n);
         std::vector<double> mrows((n + 1) * 8);
         RTM_HIP_CHECK(hipMemcpy(mrows.data(), sc.mat.p, mrows.size() * sizeof(double), hipMemcpyDeviceToHost));
-        sc.fold_flags = fold_flags_of(mrows.data(), n);
+        sc.fold_flags = fold_flags_of(mrows.data(), n) | compact_flag_of(rows.data(), n);
     }
     if (n < kGridMinSpheres) return RTM_OK;
     std::vector<double> hg(n * 4);  // the grid is built on the host: the geometry rows come back once

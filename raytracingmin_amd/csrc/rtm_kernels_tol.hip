@@ -21,6 +21,7 @@
 #define RTM_TOL 1
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -28,6 +29,19 @@
 #include "rtm_render_kernel.h"
 
 namespace rtm_tol {
+
+// The axis-signature instantiations of this unit take the search's roots without their residual step (rtm_path.h:
+// seq_sqrt_batch, LIGHT): for compact scenes seen by a camera that is within the same extent — anything else runs the plain
+// exact-n kernels with the full roots.
+static bool compact_launch(const RenderParams& P) {
+#if RTM_TOL_LIGHT_ROOTS
+    const double cam = std::sqrt(P.cam_org.x * P.cam_org.x + P.cam_org.y * P.cam_org.y + P.cam_org.z * P.cam_org.z);
+    return (P.scene.fold_flags & kSceneCompact) != 0u && cam <= kCompactExtent;
+#else
+    (void)P;
+    return true;
+#endif
+}
 
 #ifndef RTM_TOL_WPE
 #define RTM_TOL_WPE 4  // waves per SIMD of the depth-capped kernel's launch bound (A/B knob: profiles/r4/tol_wpe_ab.txt)
@@ -60,7 +74,7 @@ static void launch_n_any(const RenderParams& P, unsigned grid, size_t lds_pad, h
 #if RTM_OPT_AXIS
     const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
                                             kFoldQueueBytesLS + lds_pad);  // (launch_one_any's rule)
-    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED && table_fits) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
+    if (P.scene.n == 7 && P.scene.axis_pat == kAxisSigCornell7 && P.mode == RTM_MODE_REPAIRED && table_fits && compact_launch(P)) {  // (the shipped Cornell box: rtm_path.h, sphere_disc)
         launch_one_any<axis_unroll(7, kAxisSigCornell7), SPLIT>(P, grid, lds_pad, stream);
         return;
     }
@@ -76,7 +90,7 @@ static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipSt
     const bool table_fits = unit_table_fits(lds_table_bytes(P.scene.n) + (10 + kTrigConstCount) * sizeof(double) + 6 * 64 * sizeof(double) +
                                             kFoldQueueBytesS + 2 * 64 * sizeof(unsigned) + 64 * sizeof(unsigned long long) + lds_pad);
 #define RTM_AXIS_CASE(k, sig)                                                                   \
-    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && table_fits) { /* rtm_path.h: sphere_disc */ \
+    if (P.scene.n == k && P.scene.axis_pat == sig && P.mode == RTM_MODE_REPAIRED && table_fits && compact_launch(P)) { /* rtm_path.h: sphere_disc */ \
         launch_one<axis_unroll(k, sig), SPLIT>(P, grid, lds_pad, stream);                       \
         return;                                                                                 \
     }
@@ -97,7 +111,7 @@ static void launch_n(const RenderParams& P, unsigned grid, size_t lds_pad, hipSt
 // distance to the correctly rounded results in ulps).  32 the unscaled square root, 33 x / y by reciprocal, 34 the
 // reciprocal alone, 35 x * y + 1.0 (contracted here: the other translation unit's op 7 must not be), 36 / 37 sin / cos of the
 // branch-free sincos as compiled here, 38 one level of the fold (x * y + 0.25: must NOT be contracted), 39 / 40 sin / cos of
-// 2 pi (x 2^-24) by the quadrant-exact sequence the shading block uses (x: a draw's 24-bit integer)
+// 2 pi (x 2^-24) by the quadrant-exact sequence the shading block uses (x: a draw's 24-bit integer), 41 the search's light root
 __global__ void tol_math_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b, size_t n,
                                       double* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,6 +128,13 @@ __global__ void tol_math_probe_kernel(int op, const double* __restrict__ a, cons
         case 38: r = fold_step(d3(x, x, x), d3(y, y, y), d3(0.25, 0.25, 0.25)).y; break;
         case 39: sincos_turn24_k(TrigFromRegs{}, x, s, c); r = s; break;
         case 40: sincos_turn24_k(TrigFromRegs{}, x, s, c); r = c; break;
+        case 41: {  // the search's light root (seq_sqrt_batch<K, true>)
+            const double in[1] = {x};
+            double out1[1];
+            seq_sqrt_batch<1, true>(in, out1);
+            r = out1[0];
+            break;
+        }
         default: break;
     }
     out[i] = r;

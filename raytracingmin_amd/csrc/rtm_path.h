@@ -27,6 +27,9 @@
 #ifndef RTM_OPT_CTMODE
 #define RTM_OPT_CTMODE 1  // what an instantiation knows at compile time: its mode (axis signatures), "no planes" (SceneLds) ...
 #endif
+#ifndef RTM_TOL_LIGHT_ROOTS
+#define RTM_TOL_LIGHT_ROOTS 1  // the tolerance unit's search roots without the residual step in compact scenes (A/B switch)
+#endif
 #ifndef RTM_OPT_FOLDMUL
 #define RTM_OPT_FOLDMUL 1  // the packed folds leave a bounce level's "+ (+0, +0, +0)" out (SceneView::fold_flags; A/B switch)
 #endif
@@ -91,7 +94,7 @@ __device__ __forceinline__ double seq_sqrt(const double x) {
 #endif
 }
 // K independent roots, stage by stage (K independent dependency chains for the scheduler to interleave)
-template <int K>
+template <int K, bool LIGHT = false>
 __device__ __forceinline__ void seq_sqrt_batch(const double (&x)[K], double (&out)[K]) {
 #if RTM_TOL
     double y[K], s0[K], h0[K], r0[K], s1[K], d0[K];
@@ -103,11 +106,25 @@ __device__ __forceinline__ void seq_sqrt_batch(const double (&x)[K], double (&ou
     for (int k = 0; k < K; ++k) r0[k] = __builtin_fma(-h0[k], s0[k], 0.5);
 #pragma unroll
     for (int k = 0; k < K; ++k) s1[k] = __builtin_fma(s0[k], r0[k], s0[k]);
+    if constexpr (LIGHT) {
+        // The nearest-hit search of a COMPACT scene (SceneView::fold_flags, kSceneCompact), tolerance unit only: the roots
+        // without their residual step — s1 is good to 1.5 e^2 = 2^-45 (e = 2^-23: v_rsq_f64).  What a root decides there: which
+        // sphere is nearest (a tie within 3e-14 of a distance: as rare as the ties contraction already moves), t1 against
+        // 0.001, and the far root t2 = b + sqrt(D4) of the sphere a bounce ray starts on against 1e-5f — t2 is 0 in real
+        // arithmetic and 3e-14 |b| here, five orders below the threshold while |b| <= 1e7, which is what "compact" promises
+        // (a sphere of radius 1e9 would start hitting itself: such scenes keep the full roots).  The winner's distance carries
+        // the same 3e-14: 2e-10 of absolute error on the shipped box's walls, against hit ids that need 1e-3 to change.
+        (void)d0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) d0[k] = __builtin_fma(-s1[k], s1[k], x[k]);
+        for (int k = 0; k < K; ++k) out[k] = s1[k];
+    } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = __builtin_fma(d0[k], h0[k], s1[k]);
+        for (int k = 0; k < K; ++k) d0[k] = __builtin_fma(-s1[k], s1[k], x[k]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = __builtin_fma(d0[k], h0[k], s1[k]);
+    }
 #else
+    static_assert(!LIGHT, "light roots are the tolerance unit's");
     double y[K], s0[K], h0[K], r0[K], s1[K], h1[K], d0[K], s2[K], d1[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) y[k] = __builtin_amdgcn_rsq(x[k]);
@@ -211,7 +228,7 @@ struct MathFast {
     //               positive number) is never -0.
     // +0, subnormals and tiny normals are the cases that need ocml's pre-scaling (a tangent ray with
     // D4 = +0 has a real hit at t = b).
-    template <int K>
+    template <int K, bool LIGHT = false>
     static __device__ __forceinline__ void sqrt64_batch_hit(const double (&x)[K], double (&out)[K]) {
 #if RTM_OPT_GUARD
         // "every high word >= 0x10000000" as ONE compare of their unsigned minimum (v_min3_u32): the K
@@ -233,7 +250,7 @@ struct MathFast {
             for (int k = 0; k < K; ++k) out[k] = ::sqrt(x[k]);
             return;
         }
-        seq_sqrt_batch<K>(x, out);
+        seq_sqrt_batch<K, LIGHT>(x, out);
     }
     // one division (the plane test's t): the same sequence for a single numerator
     static __device__ __forceinline__ double div(double x, double y) {
@@ -581,6 +598,10 @@ struct SceneView {
     unsigned fold_flags = 0u;
 };
 constexpr unsigned kFoldNoLevelEmission = 1u;
+// ... and bit 1, kSceneCompact: every |centre| + radius is finite and at most 1e7 (the launcher adds the camera): what the
+// tolerance unit's light search roots ask for (seq_sqrt_batch)
+constexpr unsigned kSceneCompact = 2u;
+constexpr double kCompactExtent = 1e7;
 
 // png::PlaneObject::Intersect as this build completes it (include/rtm.h): the reference's first line
 // (src/SettingData.cpp:244), the sphere's near threshold, then the square's extent.
@@ -980,7 +1001,8 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
                     if (k0 + k < K) sphere_disc(g[k], (SIG >> (2 * (k0 + k))) & 3u, org, dir, A, b[k0 + k], D4[k0 + k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            M::template sqrt64_batch_hit<K>(D4, sq);
+            // (the tolerance unit's axis-signature instantiations are launched for compact scenes only: light roots, above)
+            M::template sqrt64_batch_hit<K, (RTM_TOL != 0) && (RTM_TOL_LIGHT_ROOTS != 0)>(D4, sq);
             accept_batch<K>(b, sq, i0, dis, hit_object);
             return;
         }

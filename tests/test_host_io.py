@@ -342,7 +342,7 @@ def test_scene_facts_the_host_finds_when_it_flattens_a_scene():
     cornell = 2 | (1 << 2) | (1 << 4) | (2 << 6) | (2 << 8) | (3 << 10) | (3 << 12)
     scenes = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes")
     box = rtm.LoadData(os.path.join(scenes, "cornellBoxSetting.json")).data
-    assert _facts(list(box.object)) == (cornell, 1)
+    assert _facts(list(box.object)) == (cornell, 3)  # (fold flag | compact)
     assert _facts(list(rtm.LoadData(os.path.join(scenes, "simpleSetting1.json")).data.object))[0] == (1 << 2) | (1 << 4) | (2 << 6) | (2 << 8)
     assert _facts(list(rtm.LoadData(os.path.join(scenes, "settingData.json")).data.object))[0] == 2 | (1 << 4)
 
@@ -355,9 +355,12 @@ def test_scene_facts_the_host_finds_when_it_flattens_a_scene():
     assert _facts([s((1, 0, 0))] * 40)[0] == int("01" * 32, 2)  # the first 32 spheres only
     # fold flags: on for diffuse non-emitters + black emitters; off for a diffuse emitter, a negative or -0 colour or emission
     light = s((0, 9, 0), col=(0, 0, 0), em=(5, 5, 5))
-    assert _facts([light, s((1, 0, 0))])[1] == 1
-    assert _facts([light, s((1, 0, 0), em=(0, 0.1, 0))])[1] == 0       # a diffuse emitter: its level adds something
-    assert _facts([light, s((1, 0, 0), col=(.5, -.2, .5))])[1] == 0     # a negative colour: a product may be -0 ... or negative
-    assert _facts([light, s((1, 0, 0), em=(0, -0.0, 0))])[1] == 0       # (x + -0 is an identity too, but the rule keeps to +0)
-    assert _facts([s((0, 9, 0), col=(0, 0, 0), em=(5, -1, 5)), s((1, 0, 0))])[1] == 0  # a path may END anywhere: no negative start
-    assert _facts([])[1] == 1 and _facts([])[0] == 0
+    assert _facts([light, s((1, 0, 0))])[1] == 3
+    assert _facts([light, s((1, 0, 0), em=(0, 0.1, 0))])[1] == 2       # a diffuse emitter: its level adds something
+    assert _facts([light, s((1, 0, 0), col=(.5, -.2, .5))])[1] == 2     # a negative colour: a product may be -0 ... or negative
+    assert _facts([light, s((1, 0, 0), em=(0, -0.0, 0))])[1] == 2       # (x + -0 is an identity too, but the rule keeps to +0)
+    assert _facts([s((0, 9, 0), col=(0, 0, 0), em=(5, -1, 5)), s((1, 0, 0))])[1] == 2  # a path may END anywhere: no negative start
+    assert _facts([])[1] == 3 and _facts([])[0] == 0
+    # compact: every |centre| + radius within 1e7
+    big = SphereObject(vec3(0, 0, 2e9), 1.9e9, Material(vec3(.5, .5, .5), vec3(0, 0, 0)))
+    assert _facts([light, big])[1] == 1 and _facts([light, s((9.9e6, 0, 0))])[1] == 3 and _facts([light, s((1.1e7, 0, 0))])[1] == 1
