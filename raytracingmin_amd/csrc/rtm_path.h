@@ -30,6 +30,9 @@
 #ifndef RTM_TOL_LIGHT_ROOTS
 #define RTM_TOL_LIGHT_ROOTS 1  // the tolerance unit's search roots without the residual step in compact scenes (A/B switch)
 #endif
+#ifndef RTM_TOL_PACKID
+#define RTM_TOL_PACKID 1  // (with the light roots: the sphere's index in the near root's last three bits — accept_batch; A/B switch)
+#endif
 #ifndef RTM_OPT_FOLDMUL
 #define RTM_OPT_FOLDMUL 1  // the packed folds leave a bounce level's "+ (+0, +0, +0)" out (SceneView::fold_flags; A/B switch)
 #endif
@@ -822,10 +825,16 @@ __device__ __forceinline__ void accept_update(const double b, const double sq, c
 #ifndef RTM_OPT_NEARFIRST
 #define RTM_OPT_NEARFIRST 1
 #endif
-template <int K>
+//   PACKID  (the tolerance unit's light-root searches: ONE chunk of at most 7 spheres from index 0, dis = DBL_MAX on entry) the
+//           sphere's index rides in the last three bits of its near root — a perturbation of at most 7 ulps, under the light
+//           root's 35 — so that v_min_f64 alone carries distance AND index (ties between equal upper bits go to the lower
+//           index, as the strict compare did; DBL_MAX's own last bits are 7: "none"): one instruction per sphere instead of
+//           three, and three integer instructions to unpack
+template <int K, bool PACKID = false>
 __device__ __forceinline__ void accept_batch(const double (&b)[K], const double (&sq)[K], const int i0, double& dis,
                                              int& hit_object) {
 #if RTM_OPT_NEARFIRST && defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!PACKID || K <= 7, "three bits of index, 7 = none");
     double t1v[K];
     unsigned long long far = 0ull;
 #pragma unroll
@@ -833,9 +842,24 @@ __device__ __forceinline__ void accept_batch(const double (&b)[K], const double 
         const double t1 = b[k] - sq[k], t2 = b[k] + sq[k];
         const unsigned long long near = __builtin_amdgcn_ballot_w64(t1 > 0.001);
         far |= __builtin_amdgcn_ballot_w64(t2 >= (double)1e-5f) & ~near;
-        t1v[k] = __hiloint2double((int)sel_u32_mask(near, (uint32_t)__double2hiint(t1), 0x7FF80000u), __double2loint(t1));
+        const uint32_t lo = PACKID ? (((uint32_t)__double2loint(t1) & ~7u) | (uint32_t)k) : (uint32_t)__double2loint(t1);
+        t1v[k] = __hiloint2double((int)sel_u32_mask(near, (uint32_t)__double2hiint(t1), 0x7FF80000u), (int)lo);
     }
-    if (far == 0ull) {
+    if constexpr (PACKID) {
+        if (far == 0ull) {
+            double best = dis;  // DBL_MAX: index field 7
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                double m;
+                asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(best), "v"(t1v[k]));
+                best = m;
+            }
+            dis = best;
+            hit_object = (int)((((uint32_t)__double2loint(best)) + 1u) & 7u) - 1;  // 7 -> -1
+            return;
+        }
+    }
+    if (!PACKID && far == 0ull) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const unsigned long long accept = __builtin_amdgcn_ballot_w64(t1v[k] < dis);
@@ -1003,7 +1027,7 @@ __device__ __forceinline__ void sphere_chunk(const Scene& sc, const int i0, cons
             }
             // (the tolerance unit's axis-signature instantiations are launched for compact scenes only: light roots, above)
             M::template sqrt64_batch_hit<K, (RTM_TOL != 0) && (RTM_TOL_LIGHT_ROOTS != 0)>(D4, sq);
-            accept_batch<K>(b, sq, i0, dis, hit_object);
+            accept_batch<K, (RTM_TOL != 0) && (RTM_TOL_LIGHT_ROOTS != 0) && (RTM_TOL_PACKID != 0)>(b, sq, i0, dis, hit_object);
             return;
         }
 #pragma unroll
